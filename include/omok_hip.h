@@ -1,0 +1,141 @@
+/*
+ * omok_hip.h -- C ABI of libomok_hip.so, the MI355X-native AlphaZero self-play engine for Omok.
+ *
+ * The reference (reinforcement-learning-kr/alpha_omok) is pure Python and has no FFI; this is
+ * the boundary a maintainer binds with ctypes. Each entry point names the
+ * reference interface it replaces (paths relative to /root/reference/2_AlphaOmok/).
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure (ao_last_error() gives
+ * the message). Buffers are caller-owned. "dev" pointers are HIP device pointers on the handle's
+ * device (e.g. torch.Tensor.data_ptr()); "host" pointers are ordinary memory. A handle is not
+ * thread-safe; all its work is queued on one HIP stream (ao_stream()).
+ *
+ * A handle owns G concurrent games. Game g has: its move list (the reference's node id without
+ * the leading 0), its search tree (structure-of-arrays arena in HBM), and its own numpy-legacy
+ * MT19937 stream (the reference's process-global np.random, main.py:60, one per game here).
+ */
+#ifndef OMOK_HIP_H
+#define OMOK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AO_ABI_VERSION 1
+
+typedef struct ao_engine ao_engine; /* search engine: G games                       */
+typedef struct ao_net ao_net;       /* policy/value ResNet (model.py PVNet) weights  */
+
+typedef struct ao_config {
+    int32_t board;      /* board edge: 3, 9 (env_small.py:18) or 15 (env_regular.py), any 3..15 */
+    int32_t win_mark;   /* 0 = reference rule: 3 if board == 3 else 5 (agents.py:46)            */
+    int32_t sims;       /* num_mcts (agents.py:43; main.py:27 N_MCTS = 400)                    */
+    int32_t inplanes;   /* IN_PLANES = 2*history+1 (main.py:34); 3, 5, 7 or 9                  */
+    int32_t games;      /* G concurrent games (1 for a drop-in ZeroAgent)                      */
+    int32_t noise;      /* Dirichlet root noise on/off (agents.py:40,49)                       */
+    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = 4*(sims+1)          */
+    int32_t device;     /* HIP device ordinal                                                  */
+    double  c_puct;     /* 0 = 5 (agents.py:48)                                                */
+    double  alpha;      /* 0 = 10/board^2 (agents.py:47)                                       */
+} ao_config;
+
+/* root status reported by ao_set_root / ao_begin_move (agents.py:82-111) */
+enum { AO_ROOT_FRESH = 0,       /* id not in the tree: num_mcts+1 simulations                  */
+       AO_ROOT_UNEXPANDED = 1,  /* id known (n == 0, no children): num_mcts simulations        */
+       AO_ROOT_EXPANDED = 2 };  /* id known and expanded: children re-noised, num_mcts sims    */
+
+const char *ao_version(void);
+int         ao_abi_version(void);
+
+/* ---- engine lifetime ---- replaces ZeroAgent.__init__ (agents.py:40-53) */
+int  ao_create(const ao_config *cfg, ao_engine **out);
+void ao_destroy(ao_engine *e);
+const char *ao_last_error(const ao_engine *e);   /* e may be NULL: error of the failed ao_create */
+void *ao_stream(ao_engine *e);                   /* hipStream_t all engine work is queued on     */
+int  ao_sync(ao_engine *e);                      /* hipStreamSynchronize                          */
+
+/* ---- per-game RNG ---- replaces np.random.seed / get_state / set_state (main.py:60).
+ * ao_seed == np.random.seed(seed) for game g (MT19937 init_genrand, pos 624, no cached gauss). */
+int ao_seed(ao_engine *e, int game, uint32_t seed);
+int ao_seed_all(ao_engine *e, const uint32_t *host_seeds /*[G]*/);
+int ao_get_rng_state(ao_engine *e, int game, uint32_t *host_mt /*[624]*/, int32_t *pos,
+                     int32_t *has_gauss, double *gauss);
+int ao_set_rng_state(ao_engine *e, int game, const uint32_t *host_mt, int32_t pos,
+                     int32_t has_gauss, double gauss);
+
+/* ---- game / tree state ---- */
+/* ZeroAgent.reset() (agents.py:55-58) for the games with mask[g] != 0 (NULL = all): clears the
+ * tree and the move list (root id becomes (0,)). */
+int ao_reset(ao_engine *e, const uint8_t *host_mask);
+/* The root_id argument of ZeroAgent.get_pi (agents.py:60,82-84): moves = root_id[1:].
+ * Re-roots the tree kept from the previous search if the new id extends the previous root id and
+ * the node exists (tree reuse); otherwise the game starts a fresh tree. The engine keeps the
+ * subtree of the last root only (what main.self_play / eval_main.del_parents ever revisit). */
+int ao_set_root(ao_engine *e, int game, const int32_t *host_moves, int32_t n, int32_t *status);
+
+/* ---- one move decision, stepwise (external evaluator) ---- replaces _init_mcts/_mcts
+ * (agents.py:82-132). Protocol per move:
+ *     ao_begin_move -> repeat ao_sims_left() times { ao_collect_leaves -> evaluate ->
+ *     ao_apply_evals } -> ao_end_move
+ * active[g] == 0 leaves game g untouched for this move (NULL = all games active). */
+int ao_begin_move(ao_engine *e, const uint8_t *host_active);
+int ao_sims_left(ao_engine *e);
+/* _selection (agents.py:134-168) for every game with simulations left, + get_state_pt of the
+ * leaf (utils.py:139-168). dev_planes_nchw: optional float32 [G][C][B][B] (the layout
+ * Agent.model expects, agents.py:175); NULL if only the engine's own network is used. */
+int ao_collect_leaves(ao_engine *e, float *dev_planes_nchw);
+/* _expansion_evaluation + _backup (agents.py:170-239) with the evaluator's outputs:
+ * dev_policy float32 [G][A] (softmax probabilities), dev_value float32 [G]. Rows of games whose
+ * leaf was terminal (or that are inactive) are ignored. */
+int ao_apply_evals(ao_engine *e, const float *dev_policy, const float *dev_value);
+/* Tail of get_pi (agents.py:64-80): visit, policy (post-noise priors of the root children) and
+ * pi = visit/visit.sum(), one-hot through utils.argmax_onehot where tau[g] == 0.
+ * Outputs are host float64 [G][A]; any may be NULL. host_tau int8 [G] (NULL = all 1). */
+int ao_end_move(ao_engine *e, const int8_t *host_tau, double *host_pi, double *host_visit,
+                double *host_policy);
+/* utils.get_action (utils.py:189-195) on game g's stream + env step (env_small.py:154-176,196)
+ * + re-rooting on the chosen child, for all active games. host_action int32 [G],
+ * host_win int32 [G] (0 playing, 1 black, 2 white, 3 draw). Games that ended keep their final
+ * position until ao_reset. Must follow ao_end_move. */
+int ao_play(ao_engine *e, int32_t *host_action, int32_t *host_win);
+
+/* ---- one move decision, fused (native network) ---- ZeroAgent.get_pi with Agent.model = net.
+ * Runs begin_move, all simulations (select -> PVNet forward -> expand/backup on one stream) and
+ * end_move. */
+int ao_search(ao_engine *e, ao_net *net, const uint8_t *host_active, const int8_t *host_tau,
+              double *host_pi, double *host_visit, double *host_policy);
+
+/* ---- introspection (tests, get_visit/get_policy, del_parents prints) ---- */
+int ao_get_moves(ao_engine *e, int game, int32_t *host_moves /*[A]*/, int32_t *n);
+/* statistics of the root's children in stored child order: action, n, w, q, p */
+int ao_get_root_children(ao_engine *e, int game, int32_t *host_action, double *host_n,
+                         double *host_w, double *host_q, double *host_p, int32_t *count);
+int ao_tree_nodes(ao_engine *e, int game, int64_t *expanded, int64_t *dict_entries);
+/* search-shape counters since the last ao_begin_move, summed over games: PUCT levels traversed,
+ * k>1 random tie-breaks, terminal leaves, evaluated leaves */
+int ao_search_stats(ao_engine *e, int64_t *levels, int64_t *ties, int64_t *terminal,
+                    int64_t *evaluated);
+
+/* ---- policy/value network ---- replaces model.PVNet(...).forward in eval() mode
+ * (model.py:76-104). Parameters are given under their state_dict names. */
+int  ao_net_create(int n_block, int inplanes, int planes, int board, int device, ao_net **out);
+void ao_net_destroy(ao_net *n);
+const char *ao_net_last_error(const ao_net *n);
+/* host float32 data in PyTorch layout (conv OIHW, linear [out][in]); num_batches_tracked is
+ * accepted and ignored. */
+int  ao_net_set_param(ao_net *n, const char *name, const float *host_data, int64_t numel);
+int  ao_net_finalize(ao_net *n); /* fold BN running stats, repack weights for the MFMA kernels */
+/* forward for `batch` positions. dev_planes_nchw float32 [batch][C][B][B] -> dev_policy
+ * [batch][A], dev_value [batch]; `stream` is a hipStream_t (NULL = default stream). */
+int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *dev_policy,
+                    float *dev_value, void *stream);
+/* average device time (ms) and launch count of the 3x3 trunk convolution kernel since the
+ * last call (HIP events on the launch stream); used by bench.py's roofline. */
+int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,155 @@
+"""Pins the CPU oracle (oracle/omok_oracle.c) against golden vectors captured from the
+unmodified reference (tools/gen_golden.py). CPU-only; these tests are what make the oracle a
+trustworthy checker for the HIP path."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def test_gv1_check_win(oracle):
+    g = load_golden("gv1_check_win")
+    for b, (n, k), w in zip(g["boards"], g["size_mark"], g["win"]):
+        assert oracle.check_win(b[:n, :n], int(k)) == int(w)
+    assert set(g["win"].tolist()) == {0, 1, 2, 3}
+
+
+def test_gv2_legal_order(oracle):
+    g = load_golden("gv2_legal_order")
+    nonasc = 0
+    for B, mv, order in zip(g["board"], g["moves"], g["order"]):
+        mv = mv[mv >= 0].astype(np.int32)
+        order = order[order >= 0]
+        got = oracle.legal_actions(mv, int(B))
+        assert got.tolist() == order.tolist()
+        nonasc += int(order.tolist() != sorted(order.tolist()))
+    assert nonasc > 50  # the CPython set-order quirk is exercised
+
+
+def test_legal_order_matches_live_cpython(oracle):
+    # Same property checked against this interpreter's own set implementation.
+    rnd = random.Random(5)
+    for B in (3, 9, 15):
+        A = B * B
+        for _ in range(400):
+            mv = rnd.sample(range(A), rnd.randint(0, A - 1))
+            ref = list({a for a in range(A)} - set(mv))
+            assert oracle.legal_actions(mv, B).tolist() == ref
+
+
+def test_gv3_state_planes(oracle):
+    g = load_golden("gv3_state_planes")
+    for i in range(int(g["count"])):
+        m = g["m%d" % i]
+        B, C, mv = int(m[0]), int(m[1]), m[2:]
+        np.testing.assert_array_equal(oracle.get_state_pt(mv, B, C), g["s%d" % i])
+        np.testing.assert_array_equal(oracle.get_board(mv, B), g["b%d" % i])
+        assert (len(mv) + 1) % 2 == (1 if int(g["t%d" % i]) == 0 else 0)
+
+
+def test_gv4_numpy_rng(oracle):
+    g = load_golden("gv4_numpy_rng")
+    ks = g["choice_k"].tolist()
+    for seed in (0, 1, 12345, 4294967295):
+        r = oracle.Rng(seed)
+        np.testing.assert_array_equal(r.state_words()[:8], g["init_%d" % seed])
+        got = [r.choice(k) for k in ks * 5]
+        assert got == g["choice_%d" % seed].tolist()
+        got = [r.random_sample() for _ in range(8)]
+        assert got == g["dbl_%d" % seed].tolist()
+        for name, alpha, k in (("dir81", 10 / 81, 81), ("dir17", 10 / 81, 17),
+                               ("dir225", 10 / 225, 225), ("dir9", 10 / 9, 9),
+                               ("dir4", 10 / 9, 4)):
+            np.testing.assert_array_equal(r.dirichlet(alpha, k), g["%s_%d" % (name, seed)])
+        r.dirichlet(1.0, 81)  # the generator drew p ~ Dirichlet(1) here
+        p = g["p_%d" % seed]
+        got = [r.choice_p(p) for _ in range(16)]
+        assert got == g["choicep_%d" % seed].tolist()
+        onehot = np.zeros(81)
+        onehot[37] = 1.0
+        assert r.choice_p(onehot) == int(g["choice1h_%d" % seed])
+        assert r.pos == int(g["end_pos_%d" % seed])
+        np.testing.assert_array_equal(r.state_words(), g["end_state_%d" % seed])
+
+
+def test_pairwise_sum_matches_numpy(oracle):
+    rng = np.random.RandomState(0)
+    for n in (9, 81, 225, 128, 129, 7):
+        for _ in range(200):
+            a = rng.rand(n) * (rng.rand(n) < 0.7)
+            assert oracle.pairwise_sum(a) == np.sum(a)
+
+
+def _check_tree_cases(oracle, g, evaluator_for_case):
+    meta = g["meta"]
+    for ci, (B, S, mode, seed, plies, tau_thres, noise, nrec, win) in enumerate(meta.tolist()):
+        ag = oracle.Agent(B, S, 5, noise=bool(noise), evaluator=evaluator_for_case(ci, mode))
+        ag.seed(seed)
+        roots = g["c%d_root" % ci]
+        for t in range(nrec):
+            root = (0,) + tuple(int(x) for x in roots[t] if x >= 0)
+            tau = 1 if t < tau_thres else 0
+            pi, visit, policy = ag.get_pi(root, tau)
+            np.testing.assert_array_equal(visit, g["c%d_visit" % ci][t], err_msg="visit c%d t%d" % (ci, t))
+            np.testing.assert_array_equal(policy, g["c%d_policy" % ci][t], err_msg="policy c%d t%d" % (ci, t))
+            np.testing.assert_array_equal(pi, g["c%d_pi" % ci][t])
+            ch = ag.children(root)
+            np.testing.assert_array_equal(ch["w"], g["c%d_w" % ci][t])
+            np.testing.assert_array_equal(ch["q"], g["c%d_q" % ci][t])
+            order = g["c%d_order" % ci][t]
+            assert ch["order"].tolist() == order[order >= 0].tolist()
+            action = ag.rng.choice_p(pi)
+            assert action == int(g["c%d_action" % ci][t])
+            assert ag.rng.pos == int(g["c%d_mt_pos" % ci][t])
+            assert int(ag.rng.state_words().astype(np.uint64).sum()) == int(g["c%d_mt_sum" % ci][t])
+            assert ag.tree_size() == int(g["c%d_tree_size" % ci][t])
+
+
+def test_gv5_tree_parity_stub(oracle):
+    g = load_golden("gv5_tree_stub")
+    _check_tree_cases(oracle, g, lambda ci, mode: "stub%d" % mode)
+    # the fixture covers draws / both winners on 3x3 and full 9x9 games
+    assert len(set(g["meta"][:, -1].tolist())) >= 2
+
+
+def test_gv5_tree_parity_deep_roots(oracle):
+    g = load_golden("gv5_tree_stub_deeproot")
+    _check_tree_cases(oracle, g, lambda ci, mode: "stub%d" % mode)
+    # at least one root lists its children in non-ascending order
+    nonasc = 0
+    for ci in range(len(g["meta"])):
+        o = g["c%d_order" % ci][0]
+        o = o[o >= 0].tolist()
+        nonasc += int(o != sorted(o))
+    assert nonasc >= 1
+
+
+def test_gv6_tree_parity_real_net_replay(oracle):
+    g = load_golden("gv6_tree_realnet")
+    ep, ev = g["eval_p"], g["eval_v"]
+    cursor = [0]
+
+    def replay(moves, planes, sim):
+        i = cursor[0]
+        cursor[0] += 1
+        return ep[i], ev[i]
+
+    _check_tree_cases(oracle, g, lambda ci, mode: replay)
+    assert cursor[0] == len(ev)
+
+
+def test_self_play_game_matches_stepwise(oracle):
+    # oo_self_play_game (main.self_play's loop) == stepping get_pi/get_action by hand
+    g = load_golden("gv5_tree_stub")
+    meta = g["meta"].tolist()
+    for ci, (B, S, mode, seed, plies, tau_thres, noise, nrec, win) in enumerate(meta):
+        if plies != 0 or not noise:
+            continue
+        ag = oracle.Agent(B, S, 5, noise=True, evaluator="stub%d" % mode)
+        moves, pis, vis, w = ag.self_play_game(seed, tau_thres)
+        assert moves.tolist() == g["c%d_action" % ci].tolist()
+        assert w == win
+        np.testing.assert_array_equal(pis, g["c%d_pi" % ci])
+        np.testing.assert_array_equal(vis, g["c%d_visit" % ci])
