@@ -1,0 +1,572 @@
+// engine.hip -- host driver of the batched self-play engine and the C ABI of include/omok_hip.h.
+//
+// Per move decision (ZeroAgent.get_pi, agents.py:60-132) the host does exactly three things:
+//   1. draws each game's Dirichlet noise from the game's own MT19937 stream (host_rng.hpp;
+//      the state is read back from HBM, 2.5 KB per game per move, and written back),
+//   2. queues the kernels: k_begin_move, then per simulation k_select -> evaluator ->
+//      k_expand_backup, then k_end_move (and k_play for self-play),
+//   3. copies the [G][A] result vectors back.
+// Everything else lives in HBM and in the kernels of tree_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/omok_hip.h"
+#include "engine_types.hpp"
+#include "host_rng.hpp"
+
+namespace ao {
+void launch_select(const TreeParams& p, hipStream_t s);
+void launch_expand_backup(const TreeParams& p, hipStream_t s);
+void launch_begin_move(const TreeParams& p, hipStream_t s);
+void launch_end_move(const TreeParams& p, hipStream_t s);
+void launch_play(const TreeParams& p, hipStream_t s);
+void launch_walk(const TreeParams& p, int g, const int32_t* extra, int m, int prev_known,
+                 int32_t* status_out, hipStream_t s);
+void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
+// net.hip
+int net_forward_il(ao_net* n, const float* in_il, int groups, float* policy, float* value,
+                   hipStream_t s);
+int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why);
+}  // namespace ao
+
+static thread_local std::string g_create_error;
+
+struct ao_engine {
+    ao_config cfg{};
+    ao::TreeParams tp{};
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int A = 0, Ap = 0, G = 0, Gp = 0, S = 0;
+    std::vector<void*> allocs;
+    // device scratch
+    uint8_t* d_active = nullptr; int8_t* d_tau = nullptr; int32_t* d_extra = nullptr;
+    int32_t* d_status = nullptr; uint8_t* d_mask = nullptr;
+    float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
+    // host mirrors
+    std::vector<std::vector<int32_t>> moves;
+    std::vector<int32_t> status;     // AO_ROOT_*
+    std::vector<int32_t> over;       // win index once the game ended
+    std::vector<uint8_t> active;
+    std::vector<int32_t> has_gauss; std::vector<double> gauss;
+    uint32_t* h_mt = nullptr; int32_t* h_pos = nullptr; double* h_noise = nullptr;  // pinned
+    double* h_out = nullptr;         // pinned [3][G][A]
+    int32_t* h_i32 = nullptr;        // pinned [4][G]
+    int sims_left = 0;
+    bool in_move = false, ended = false;
+
+    int fail(const std::string& m) { err = m; return 1; }
+};
+
+#define AO_HIP(e, call)                                                                       \
+    do {                                                                                      \
+        hipError_t st_ = (call);                                                              \
+        if (st_ != hipSuccess)                                                                \
+            return (e)->fail(std::string(#call) + ": " + hipGetErrorString(st_));             \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(ao_engine* e, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t st = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
+    if (st != hipSuccess)
+        return e->fail(std::string("hipMalloc(") + std::to_string(count * sizeof(T)) + " B): " +
+                       hipGetErrorString(st));
+    e->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return 0;
+}
+
+extern "C" {
+
+const char* ao_version(void) { return "alpha_omok_amd 0.1 (gfx950)"; }
+int ao_abi_version(void) { return AO_ABI_VERSION; }
+
+const char* ao_last_error(const ao_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+void* ao_stream(ao_engine* e) { return e ? e->stream : nullptr; }
+
+int ao_sync(ao_engine* e) {
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ao_set_stream(ao_engine* e, void* stream) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    e->stream = stream ? static_cast<hipStream_t>(stream) : e->own_stream;
+    return 0;
+}
+
+void ao_destroy(ao_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    if (e->h_mt) hipHostFree(e->h_mt);
+    if (e->h_pos) hipHostFree(e->h_pos);
+    if (e->h_noise) hipHostFree(e->h_noise);
+    if (e->h_out) hipHostFree(e->h_out);
+    if (e->h_i32) hipHostFree(e->h_i32);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+static int create_impl(ao_engine* e, const ao_config* cfg) {
+    e->cfg = *cfg;
+    ao_config& c = e->cfg;
+    if (c.board < 3 || c.board > ao::kMaxBoard) return e->fail("board must be in 3..15");
+    if (c.win_mark <= 0) c.win_mark = (c.board == 3) ? 3 : 5;
+    if (c.win_mark > 5) return e->fail("win_mark must be <= 5");
+    if (c.sims < 1) return e->fail("sims must be >= 1");
+    if (c.inplanes < 3 || c.inplanes > 9 || (c.inplanes % 2) == 0) return e->fail("inplanes must be 3, 5, 7 or 9");
+    if (c.games < 1) return e->fail("games must be >= 1");
+    if (c.c_puct == 0.0) c.c_puct = 5.0;
+    if (c.alpha == 0.0) c.alpha = 10.0 / static_cast<double>(c.board * c.board);
+    if (c.node_cap <= 0) c.node_cap = 4 * (c.sims + 1);
+    if (c.node_cap < c.sims + 2) return e->fail("node_cap must be at least sims + 2");
+    if (c.node_cap > 15000) return e->fail("node_cap must be <= 15000");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return e->fail("no HIP device available");
+    if (c.device < 0 || c.device >= ndev) return e->fail("device ordinal out of range");
+    AO_HIP(e, hipSetDevice(c.device));
+    AO_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+
+    const int A = c.board * c.board, Ap = (A + 15) / 16 * 16, G = c.games;
+    const int Gp = (G + ao::kGroup - 1) / ao::kGroup * ao::kGroup;
+    e->A = A; e->Ap = Ap; e->G = G; e->Gp = Gp; e->S = c.sims;
+    ao::TreeParams& p = e->tp;
+    p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
+    p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
+    p.nchq = (((c.inplanes + 3) / 4) + 1) & ~1;  // channel quads, consumed in pairs by the conv kernel
+    p.c_puct = c.c_puct;
+
+    const size_t slots = static_cast<size_t>(2) * G * p.cap;
+    if (dev_alloc(e, &p.N, slots * Ap) || dev_alloc(e, &p.W, slots * Ap) || dev_alloc(e, &p.Q, slots * Ap) ||
+        dev_alloc(e, &p.P, slots * Ap) || dev_alloc(e, &p.CH, slots * Ap) || dev_alloc(e, &p.ACT, slots * Ap) ||
+        dev_alloc(e, &p.meta, slots))
+        return 1;
+    if (dev_alloc(e, &p.cur, G) || dev_alloc(e, &p.root_node, G) || dev_alloc(e, &p.nodes_used, G) ||
+        dev_alloc(e, &p.rootpos, G) || dev_alloc(e, &p.mt, static_cast<size_t>(G) * 624) ||
+        dev_alloc(e, &p.mtpos, G) || dev_alloc(e, &p.noise_buf, static_cast<size_t>(G) * Ap) ||
+        dev_alloc(e, &p.sims_target, G) || dev_alloc(e, &p.sims_done, G) || dev_alloc(e, &p.gflags, G) ||
+        dev_alloc(e, &p.rstatus, G) || dev_alloc(e, &p.leaf_status, G) || dev_alloc(e, &p.path_len, G) ||
+        dev_alloc(e, &p.path_node, static_cast<size_t>(G) * p.maxd) ||
+        dev_alloc(e, &p.path_edge, static_cast<size_t>(G) * p.maxd) || dev_alloc(e, &p.leaf_pos, G) ||
+        dev_alloc(e, &p.err, G) || dev_alloc(e, &p.stats, 4) ||
+        dev_alloc(e, &p.out_pi, static_cast<size_t>(G) * A) || dev_alloc(e, &p.out_visit, static_cast<size_t>(G) * A) ||
+        dev_alloc(e, &p.out_policy, static_cast<size_t>(G) * A) || dev_alloc(e, &p.action, G) ||
+        dev_alloc(e, &p.win, G) || dev_alloc(e, &e->d_active, G) || dev_alloc(e, &e->d_tau, G) ||
+        dev_alloc(e, &e->d_extra, A + 1) || dev_alloc(e, &e->d_status, 4) || dev_alloc(e, &e->d_mask, G))
+        return 1;
+    // evaluation batches of the native network: interleaved input, policy/value rows for Gp boards
+    float* il = nullptr;
+    if (dev_alloc(e, &il, static_cast<size_t>(Gp) * A * p.nchq * 4) ||
+        dev_alloc(e, &e->d_policy, static_cast<size_t>(Gp) * A) || dev_alloc(e, &e->d_value, Gp))
+        return 1;
+    AO_HIP(e, hipMemsetAsync(il, 0, static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float), e->stream));
+    p.batch_il = il;
+    p.tau = e->d_tau;
+    p.active = e->d_active;
+
+    // np.sqrt(total_n) for every reachable integer total (correctly rounded by IEEE sqrt)
+    const int lut_n = c.sims * (A + 2) + 8;
+    std::vector<double> lut(lut_n);
+    for (int i = 0; i < lut_n; ++i) lut[i] = std::sqrt(static_cast<double>(i));
+    double* d_lut = nullptr;
+    if (dev_alloc(e, &d_lut, lut_n)) return 1;
+    AO_HIP(e, hipMemcpy(d_lut, lut.data(), sizeof(double) * lut_n, hipMemcpyHostToDevice));
+    p.sqrt_lut = d_lut; p.sqrt_lut_n = lut_n;
+
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_mt), sizeof(uint32_t) * 624 * G, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_pos), sizeof(int32_t) * G, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_noise), sizeof(double) * G * Ap, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), sizeof(double) * 3 * G * A, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_i32), sizeof(int32_t) * 4 * G, hipHostMallocDefault));
+    std::memset(e->h_noise, 0, sizeof(double) * G * Ap);
+
+    e->moves.assign(G, {});
+    e->status.assign(G, AO_ROOT_FRESH);
+    e->over.assign(G, 0);
+    e->active.assign(G, 1);
+    e->has_gauss.assign(G, 0);
+    e->gauss.assign(G, 0.0);
+    for (int g = 0; g < G; ++g) {
+        ao::HostMT::seed(e->h_mt + static_cast<size_t>(g) * 624, static_cast<uint32_t>(g));
+        e->h_pos[g] = 624;
+    }
+    AO_HIP(e, hipMemcpyAsync(p.mt, e->h_mt, sizeof(uint32_t) * 624 * G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(p.mtpos, e->h_pos, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 4, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.noise_buf, 0, sizeof(double) * G * Ap, e->stream));
+    ao::launch_reset(p, nullptr, e->stream);
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ao_create(const ao_config* cfg, ao_engine** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return 1; }
+    ao_engine* e = new ao_engine();
+    if (create_impl(e, cfg)) {
+        g_create_error = e->err;
+        ao_destroy(e);
+        *out = nullptr;
+        return 1;
+    }
+    *out = e;
+    return 0;
+}
+
+// ---- RNG -------------------------------------------------------------------------------------
+int ao_set_rng_state(ao_engine* e, int g, const uint32_t* mt, int32_t pos, int32_t has_gauss, double gauss) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipMemcpyAsync(e->tp.mt + static_cast<size_t>(g) * 624, mt, sizeof(uint32_t) * 624,
+                             hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(e->tp.mtpos + g, &pos, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    e->has_gauss[g] = has_gauss;
+    e->gauss[g] = gauss;
+    return 0;
+}
+
+int ao_get_rng_state(ao_engine* e, int g, uint32_t* mt, int32_t* pos, int32_t* has_gauss, double* gauss) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipMemcpyAsync(mt, e->tp.mt + static_cast<size_t>(g) * 624, sizeof(uint32_t) * 624,
+                             hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipMemcpyAsync(pos, e->tp.mtpos + g, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    if (has_gauss) *has_gauss = e->has_gauss[g];
+    if (gauss) *gauss = e->gauss[g];
+    return 0;
+}
+
+int ao_seed(ao_engine* e, int g, uint32_t seed) {
+    std::vector<uint32_t> mt(624);
+    ao::HostMT::seed(mt.data(), seed);
+    return ao_set_rng_state(e, g, mt.data(), 624, 0, 0.0);
+}
+
+int ao_seed_all(ao_engine* e, const uint32_t* seeds) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    for (int g = 0; g < e->G; ++g) {
+        ao::HostMT::seed(e->h_mt + static_cast<size_t>(g) * 624, seeds[g]);
+        e->h_pos[g] = 624;
+        e->has_gauss[g] = 0;
+        e->gauss[g] = 0.0;
+    }
+    AO_HIP(e, hipMemcpyAsync(e->tp.mt, e->h_mt, sizeof(uint32_t) * 624 * e->G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(e->tp.mtpos, e->h_pos, sizeof(int32_t) * e->G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- game / tree state -----------------------------------------------------------------------
+int ao_reset(ao_engine* e, const uint8_t* mask) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    const uint8_t* dmask = nullptr;
+    if (mask) {
+        AO_HIP(e, hipMemcpyAsync(e->d_mask, mask, e->G, hipMemcpyHostToDevice, e->stream));
+        dmask = e->d_mask;
+    }
+    ao::launch_reset(e->tp, dmask, e->stream);
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    for (int g = 0; g < e->G; ++g) {
+        if (mask && !mask[g]) continue;
+        e->moves[g].clear();
+        e->status[g] = AO_ROOT_FRESH;
+        e->over[g] = 0;
+    }
+    e->in_move = false;
+    return 0;
+}
+
+int ao_set_root(ao_engine* e, int g, const int32_t* mv, int32_t n, int32_t* status) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    if (n < 0 || n > e->A) return e->fail("move list too long");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    std::vector<int32_t>& cur = e->moves[g];
+    bool extends = static_cast<size_t>(n) >= cur.size() &&
+                   std::equal(cur.begin(), cur.end(), mv);
+    int first = 0;
+    int prev_known = (e->status[g] != AO_ROOT_FRESH) ? 1 : 0;
+    if (!extends) {
+        std::vector<uint8_t> mask(e->G, 0);
+        mask[g] = 1;
+        if (ao_reset(e, mask.data())) return 1;
+        prev_known = 0;
+    } else {
+        first = static_cast<int>(cur.size());
+    }
+    const int m = n - first;
+    if (m > 0)
+        AO_HIP(e, hipMemcpyAsync(e->d_extra, mv + first, sizeof(int32_t) * m, hipMemcpyHostToDevice, e->stream));
+    ao::launch_walk(e->tp, g, e->d_extra, m, prev_known, e->d_status, e->stream);
+    int32_t st = 0;
+    AO_HIP(e, hipMemcpyAsync(&st, e->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    if (st < 0) {
+        std::vector<uint8_t> mask(e->G, 0);
+        mask[g] = 1;
+        ao_reset(e, mask.data());
+        return e->fail("ao_set_root: illegal move in the id (occupied cell or out of range)");
+    }
+    cur.assign(mv, mv + n);
+    e->status[g] = st;
+    e->over[g] = 0;
+    if (status) *status = st;
+    return 0;
+}
+
+int ao_get_moves(ao_engine* e, int g, int32_t* out, int32_t* n) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    std::copy(e->moves[g].begin(), e->moves[g].end(), out);
+    *n = static_cast<int32_t>(e->moves[g].size());
+    return 0;
+}
+
+// ---- one move decision -----------------------------------------------------------------------
+int ao_begin_move(ao_engine* e, const uint8_t* active) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    const int G = e->G, A = e->A, Ap = e->Ap;
+    ao::TreeParams& p = e->tp;
+    int32_t* target = e->h_i32;
+    int32_t* flags = e->h_i32 + G;
+    int maxt = 0;
+    for (int g = 0; g < G; ++g) {
+        e->active[g] = (active ? active[g] : 1) && !e->over[g];
+        target[g] = 0;
+        flags[g] = 0;
+        if (!e->active[g]) continue;
+        target[g] = (e->status[g] == AO_ROOT_FRESH) ? e->S + 1 : e->S;  // agents.py:107-111
+        flags[g] = (p.noise && e->status[g] == AO_ROOT_EXPANDED) ? 1 : 0;
+        maxt = std::max(maxt, target[g]);
+    }
+    if (p.noise) {
+        // The Dirichlet draw is the first consumer of the stream in a move in every case:
+        // re-noise of an inherited root (agents.py:97) or the root expansion of sim 0 (:194).
+        AO_HIP(e, hipMemcpyAsync(e->h_mt, p.mt, sizeof(uint32_t) * 624 * G, hipMemcpyDeviceToHost, e->stream));
+        AO_HIP(e, hipMemcpyAsync(e->h_pos, p.mtpos, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+        AO_HIP(e, hipStreamSynchronize(e->stream));
+        const double alpha = e->cfg.alpha;
+        auto work = [&](int g0, int g1) {
+            for (int g = g0; g < g1; ++g) {
+                if (!e->active[g]) continue;
+                ao::HostMT r{e->h_mt + static_cast<size_t>(g) * 624, e->h_pos + g, &e->has_gauss[g], &e->gauss[g]};
+                const int k = A - static_cast<int>(e->moves[g].size());
+                r.dirichlet(alpha, k, e->h_noise + static_cast<size_t>(g) * Ap);
+            }
+        };
+        unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        if (G < 64) nt = 1;
+        if (nt <= 1) {
+            work(0, G);
+        } else {
+            std::vector<std::thread> th;
+            const int per = (G + static_cast<int>(nt) - 1) / static_cast<int>(nt);
+            for (unsigned t = 0; t < nt; ++t) {
+                const int g0 = static_cast<int>(t) * per, g1 = std::min(G, g0 + per);
+                if (g0 < g1) th.emplace_back(work, g0, g1);
+            }
+            for (auto& t : th) t.join();
+        }
+        AO_HIP(e, hipMemcpyAsync(p.mt, e->h_mt, sizeof(uint32_t) * 624 * G, hipMemcpyHostToDevice, e->stream));
+        AO_HIP(e, hipMemcpyAsync(p.mtpos, e->h_pos, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
+        AO_HIP(e, hipMemcpyAsync(p.noise_buf, e->h_noise, sizeof(double) * G * Ap, hipMemcpyHostToDevice, e->stream));
+    }
+    AO_HIP(e, hipMemcpyAsync(p.sims_target, target, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(p.gflags, flags, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(e->d_active, e->active.data(), G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 4, e->stream));
+    ao::launch_begin_move(p, e->stream);
+    // the pinned staging buffers are reused by the next call: make sure the copies are done
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    e->sims_left = maxt;
+    e->in_move = true;
+    e->ended = false;
+    return 0;
+}
+
+int ao_sims_left(ao_engine* e) { return e->sims_left; }
+
+int ao_collect_leaves(ao_engine* e, float* dev_planes_nchw) {
+    if (!e->in_move) return e->fail("ao_collect_leaves outside ao_begin_move/ao_end_move");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    ao::TreeParams p = e->tp;
+    p.batch_nchw = dev_planes_nchw;
+    ao::launch_select(p, e->stream);
+    AO_HIP(e, hipGetLastError());
+    return 0;
+}
+
+int ao_apply_evals(ao_engine* e, const float* dev_policy, const float* dev_value) {
+    if (!e->in_move) return e->fail("ao_apply_evals outside ao_begin_move/ao_end_move");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    ao::TreeParams p = e->tp;
+    p.policy = dev_policy;
+    p.value = dev_value;
+    ao::launch_expand_backup(p, e->stream);
+    AO_HIP(e, hipGetLastError());
+    if (e->sims_left > 0) --e->sims_left;
+    return 0;
+}
+
+static int check_game_errors(ao_engine* e) {
+    int32_t* herr = e->h_i32 + 2 * e->G;
+    AO_HIP(e, hipMemcpyAsync(herr, e->tp.err, sizeof(int32_t) * e->G, hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    for (int g = 0; g < e->G; ++g) {
+        if (!herr[g]) continue;
+        std::string m = "game " + std::to_string(g) + ":";
+        if (herr[g] & ao::ERR_NODE_CAP) m += " tree arena full (raise ao_config.node_cap)";
+        if (herr[g] & ao::ERR_PATH) m += " inconsistent selection path";
+        if (herr[g] & ao::ERR_BAD_MOVE) m += " move onto an occupied cell";
+        return e->fail(m);
+    }
+    return 0;
+}
+
+int ao_end_move(ao_engine* e, const int8_t* tau, double* pi, double* visit, double* policy) {
+    if (!e->in_move) return e->fail("ao_end_move without ao_begin_move");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    const int G = e->G, A = e->A;
+    ao::TreeParams p = e->tp;
+    if (tau) {
+        AO_HIP(e, hipMemcpyAsync(e->d_tau, tau, G, hipMemcpyHostToDevice, e->stream));
+        p.tau = e->d_tau;
+    } else {
+        p.tau = nullptr;
+    }
+    ao::launch_end_move(p, e->stream);
+    const size_t n = static_cast<size_t>(G) * A;
+    if (pi) AO_HIP(e, hipMemcpyAsync(e->h_out, p.out_pi, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    if (visit) AO_HIP(e, hipMemcpyAsync(e->h_out + n, p.out_visit, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    if (policy) AO_HIP(e, hipMemcpyAsync(e->h_out + 2 * n, p.out_policy, sizeof(double) * n, hipMemcpyDeviceToHost, e->stream));
+    if (check_game_errors(e)) return 1;  // synchronises the stream
+    if (pi) std::memcpy(pi, e->h_out, sizeof(double) * n);
+    if (visit) std::memcpy(visit, e->h_out + n, sizeof(double) * n);
+    if (policy) std::memcpy(policy, e->h_out + 2 * n, sizeof(double) * n);
+    // after a search every searched root is expanded (it was expanded by sim 0 at the latest)
+    for (int g = 0; g < G; ++g)
+        if (e->active[g]) e->status[g] = AO_ROOT_EXPANDED;
+    e->in_move = false;
+    e->ended = true;
+    return 0;
+}
+
+int ao_play(ao_engine* e, int32_t* action, int32_t* win) {
+    if (!e->ended) return e->fail("ao_play must follow ao_end_move");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    const int G = e->G;
+    ao::launch_play(e->tp, e->stream);
+    int32_t* ha = e->h_i32;
+    int32_t* hw = e->h_i32 + G;
+    int32_t* hs = e->h_i32 + 3 * G;
+    AO_HIP(e, hipMemcpyAsync(ha, e->tp.action, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipMemcpyAsync(hw, e->tp.win, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipMemcpyAsync(hs, e->tp.rstatus, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+    if (check_game_errors(e)) return 1;
+    for (int g = 0; g < G; ++g) {
+        if (!e->active[g]) {
+            if (action) action[g] = -1;
+            if (win) win[g] = e->over[g];
+            continue;
+        }
+        e->moves[g].push_back(ha[g]);
+        e->status[g] = hs[g];
+        e->over[g] = hw[g];
+        if (action) action[g] = ha[g];
+        if (win) win[g] = hw[g];
+    }
+    e->ended = false;
+    return 0;
+}
+
+int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* tau, double* pi,
+              double* visit, double* policy) {
+    if (!net) return e->fail("ao_search: null network");
+    std::string why;
+    if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
+    if (ao_begin_move(e, active)) return 1;
+    while (e->sims_left > 0) {
+        if (ao_collect_leaves(e, nullptr)) return 1;
+        if (ao::net_forward_il(net, e->tp.batch_il, e->Gp / ao::kGroup, e->d_policy, e->d_value, e->stream))
+            return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
+        if (ao_apply_evals(e, e->d_policy, e->d_value)) return 1;
+    }
+    return ao_end_move(e, tau, pi, visit, policy);
+}
+
+// ---- introspection ---------------------------------------------------------------------------
+int ao_get_root_children(ao_engine* e, int g, int32_t* act, double* n, double* w, double* q, double* pr,
+                         int32_t* count) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    int32_t cur = 0, root = -1;
+    AO_HIP(e, hipMemcpy(&cur, e->tp.cur + g, 4, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(&root, e->tp.root_node + g, 4, hipMemcpyDeviceToHost));
+    *count = 0;
+    if (root < 0) return 0;
+    const size_t slot = ao::node_slot(e->tp, cur, g, root);
+    ao::Pos m;
+    AO_HIP(e, hipMemcpy(&m, e->tp.meta + slot, sizeof(m), hipMemcpyDeviceToHost));
+    const int L = m.nchild;
+    std::vector<int32_t> hn(L); std::vector<float> hw(L), hq(L); std::vector<double> hp(L); std::vector<uint8_t> ha(L);
+    const size_t eb = slot * e->Ap;
+    AO_HIP(e, hipMemcpy(hn.data(), e->tp.N + eb, 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hw.data(), e->tp.W + eb, 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hq.data(), e->tp.Q + eb, 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hp.data(), e->tp.P + eb, 8 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(ha.data(), e->tp.ACT + eb, L, hipMemcpyDeviceToHost));
+    for (int i = 0; i < L; ++i) {
+        if (act) act[i] = ha[i];
+        if (n) n[i] = hn[i];
+        if (w) w[i] = hw[i];
+        if (q) q[i] = hq[i];
+        if (pr) pr[i] = hp[i];
+    }
+    *count = L;
+    return 0;
+}
+
+int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries) {
+    if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    int32_t cur = 0, used = 0;
+    AO_HIP(e, hipMemcpy(&cur, e->tp.cur + g, 4, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(&used, e->tp.nodes_used + g, 4, hipMemcpyDeviceToHost));
+    if (expanded) *expanded = used;
+    if (dict_entries) {
+        std::vector<ao::Pos> metas(used);
+        if (used) AO_HIP(e, hipMemcpy(metas.data(), e->tp.meta + ao::node_slot(e->tp, cur, g, 0), sizeof(ao::Pos) * used, hipMemcpyDeviceToHost));
+        int64_t t = used ? 1 : 0;
+        for (const ao::Pos& m : metas) t += m.nchild;
+        *dict_entries = t;
+    }
+    return 0;
+}
+
+int ao_search_stats(ao_engine* e, int64_t* levels, int64_t* ties, int64_t* terminal, int64_t* evaluated) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    unsigned long long h[4];
+    AO_HIP(e, hipMemcpyAsync(h, e->tp.stats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    if (levels) *levels = static_cast<int64_t>(h[0]);
+    if (ties) *ties = static_cast<int64_t>(h[1]);
+    if (terminal) *terminal = static_cast<int64_t>(h[2]);
+    if (evaluated) *evaluated = static_cast<int64_t>(h[3]);
+    return 0;
+}
+
+}  // extern "C"

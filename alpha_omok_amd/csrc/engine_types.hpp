@@ -1,0 +1,88 @@
+// engine_types.hpp -- POD types shared by the tree kernels, the network kernels and the host
+// driver of libomok_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ao {
+
+constexpr int kBBWords = 4;        // 4 x u64 = 256 bits >= 15*15 cells
+constexpr int kMaxBoard = 15;
+constexpr int kMaxCells = kMaxBoard * kMaxBoard;
+constexpr int kLastMoves = 8;      // history kept for the input planes (C <= 9)
+constexpr int kGroup = 32;         // boards per MFMA column group (32x32x2 f32 MFMA, N = boards)
+
+// A board position. bb[0] = black stones, bb[1] = white stones, bit index = row*B + col
+// (the reference's action index, utils.py:153-154). last[i] = move (ply - i), 0xFF if none.
+struct Pos {
+    uint64_t bb[2][kBBWords];
+    int16_t ply;
+    int16_t nchild;   // only meaningful inside a node record
+    uint8_t last[kLastMoves];
+    uint32_t pad_;
+};
+static_assert(sizeof(Pos) == 80, "Pos layout");
+
+// child-link codes in the CH edge array
+constexpr int32_t CH_UNVISITED = -1;  // reference: child record exists with n == 0
+constexpr int32_t CH_TERMINAL = -2;   // visited child whose position ends the game
+
+// leaf status written by the select kernel for the expand/backup kernel
+enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3 };
+
+// per-game error bits
+enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
+
+// Everything a tree kernel needs, passed by value.
+//
+// Tree arena (structure of arrays in HBM): two arenas per game (ping-pong across re-rooting),
+// each `cap` expanded nodes; a node owns Ap edge slots (A padded to 16). Edge arrays are
+// indexed [(arena*G + g)*cap + node][edge], edge = position in the node's stored child order
+// (the order of utils.legal_actions, agents.py:182,212).
+//   N  int32   visit count   (reference 'n', an integer-valued python float)
+//   W  float   total value   (reference 'w', np.float32 under numpy 2.x)
+//   Q  float   mean value    (reference 'q', np.float32)
+//   P  double  prior         (reference 'p', np.float64)
+//   CH int32   expanded-child node index, CH_UNVISITED or CH_TERMINAL
+//   ACT uint8  action index of the edge
+struct TreeParams {
+    int B, A, Ap, C, win_mark, G, cap, maxd, noise;
+    int nchq;  // channel quads of the interleaved input batch: ceil(C/4) rounded up to even
+    double c_puct;
+    // arena
+    int32_t* N; float* W; float* Q; double* P; int32_t* CH; uint8_t* ACT; Pos* meta;
+    // per game
+    int32_t* cur;         // which arena is live
+    int32_t* root_node;   // node index of the search root, -1 if the root is not expanded
+    int32_t* nodes_used;
+    Pos* rootpos;         // position of the root (= real game position)
+    uint32_t* mt;         // [G][624] MT19937 state
+    int32_t* mtpos;       // [G]
+    double* noise_buf;    // [G][Ap] Dirichlet draw of this move (child order)
+    int32_t* sims_target; int32_t* sims_done;
+    int32_t* gflags;      // bit0: apply re-noise in begin_move (host-owned)
+    int32_t* rstatus;     // root status after k_play: 0 fresh, 1 known/unexpanded, 2 expanded
+    // per simulation scratch
+    int32_t* leaf_status; int32_t* path_len; int32_t* path_node; int16_t* path_edge; Pos* leaf_pos;
+    int32_t* err;
+    unsigned long long* stats;  // [4]: levels, ties, terminal leaves, evaluated leaves
+    const double* sqrt_lut; int sqrt_lut_n;
+    // evaluation batch
+    float* batch_il;      // interleaved [grp][cell][cq][32][4] (native network input) or null
+    float* batch_nchw;    // [G][C][B][B] or null
+    const float* policy;  // [G][A]
+    const float* value;   // [G]
+    // move results
+    double* out_pi; double* out_visit; double* out_policy;  // [G][A]
+    const int8_t* tau;    // [G]
+    int32_t* action; int32_t* win;  // [G]
+    const uint8_t* active; // [G]
+};
+
+__host__ __device__ inline size_t node_slot(const TreeParams& p, int arena, int g, int node) {
+    return (static_cast<size_t>(arena) * p.G + g) * p.cap + node;
+}
+
+}  // namespace ao

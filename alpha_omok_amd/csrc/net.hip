@@ -1,0 +1,604 @@
+// net.hip -- policy/value ResNet forward (model.py:76-104 PVNet, eval mode) for gfx950.
+//
+// Layout. Activations live in HBM as   act[grp][cell][cq][b][4]   (float32), where a group is
+// 32 boards (b), cq = channel/4. One (cell, cq) slab is 32 boards x 16 B = 512 contiguous
+// bytes, which is exactly one half-wave's B-operand fragment of v_mfma_f32_32x32x2_f32 with the
+// BOARDS as the MFMA N dimension:
+//     D[cout 32][board 32] += Wt[cout 32][k 2] * X[k 2][board 32]
+// A lane loads 16 B = 4 consecutive input channels of its board (lanes 0-31: quad cq0, lanes
+// 32-63: quad cq0+1) and issues 4 MFMAs, MFMA t consuming the k-pair {4*cq0+t, 4*cq0+4+t}.
+// Weights are repacked to wt[tap][cq][cout][4] so the A fragment is the same 16-B-per-lane,
+// 512-B-contiguous load. Every fragment load and every output store is a full-line coalesced
+// dwordx4 access; no LDS and no im2col buffer are needed (the "im2col" is the tap loop).
+//
+// Because the 32 rows of an MFMA tile are 32 different boards at the SAME cell, a tap that
+// falls outside the board is outside for the whole tile and is skipped: 625 of the 729
+// (cell, tap) pairs of a 9x9 board do work, the zero padding costs nothing.
+//
+// One workgroup = one board row of one group (BW output cells), all output channels:
+// wave w owns output-channel tile w (32 couts) and keeps BW accumulator tiles (16 VGPR each).
+// The epilogue fuses BatchNorm (running stats folded to scale/shift), the residual add and ReLU.
+//
+// The 3x3 stack is >99.9 % of the FLOPs; the heads (1x1 convs, FCs, softmax, tanh) are small
+// VALU kernels on the same layout.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/omok_hip.h"
+#include "engine_types.hpp"
+
+namespace ao {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Frag {
+    float v[4];
+};
+
+__device__ __forceinline__ Frag ld_frag(const float4* p) {
+    const float4 t = *p;
+    Frag f;
+    f.v[0] = t.x; f.v[1] = t.y; f.v[2] = t.z; f.v[3] = t.w;
+    return f;
+}
+
+// XCD-aware block id remap: consecutive virtual ids (rows of one group, neighbouring groups)
+// run on one XCD and share its L2 (blocks are dispatched round-robin over the 8 XCDs).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int NX>
+struct StepRegs {
+    Frag x[NX];
+    Frag w[3];
+};
+
+// 3x3 convolution, padding 1, no bias (model.py:6-10) + folded BatchNorm + optional residual
+// + ReLU. in: [grp][A][CQI][32] float4, wt: [9][CQI][COUT] float4, out/res: [grp][A][COUT/4][32].
+// A workgroup computes XT consecutive cells of one board row (XT == BW: the whole row).
+template <int BW, int XT, bool RES>
+__global__ __launch_bounds__(256) void k_conv3x3(const float4* __restrict__ in,
+                                                 const float4* __restrict__ wt,
+                                                 const float4* __restrict__ scale,
+                                                 const float4* __restrict__ shift,
+                                                 const float4* res, float4* out, int CQI, int COUT,
+                                                 int nblk) {
+    constexpr int A = BW * BW;
+    constexpr int NXT = (BW + XT - 1) / XT;
+    constexpr int NX = XT + 2;
+    const int vid = xcd_remap(blockIdx.x, nblk);
+    const int grp = vid / (BW * NXT);
+    const int rem = vid - grp * (BW * NXT);
+    const int y = rem / NXT;
+    const int x0 = (NXT == 1) ? 0 : (rem - y * NXT) * XT;
+    const int lane = threadIdx.x & 63;
+    const int ct = threadIdx.x >> 6;  // output-channel tile of this wave
+    const int half = lane >> 5;
+    const int b = lane & 31;
+    const int rlo = (y == 0) ? 1 : 0;
+    const int rhi = (y == BW - 1) ? 1 : 2;
+    const int nrows = rhi - rlo + 1;
+    const int nsteps = (CQI >> 1) * nrows;
+
+    f32x16 acc[XT];
+#pragma unroll
+    for (int i = 0; i < XT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const size_t in_grp = static_cast<size_t>(grp) * A;
+
+    auto load = [&](int s, StepRegs<NX>& R) {
+        const int cqp = s / nrows;
+        const int r = rlo + (s - cqp * nrows);
+        const int yy = y - 1 + r;
+        const int cq = cqp * 2 + half;
+        const float4* xp = in + ((in_grp + static_cast<size_t>(yy) * BW) * CQI + cq) * kGroup + b;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int xi = x0 - 1 + j;
+            if (xi >= 0 && xi < BW) R.x[j] = ld_frag(xp + static_cast<size_t>(xi) * CQI * kGroup);
+        }
+        const float4* wp = wt + (static_cast<size_t>(r * 3) * CQI + cq) * COUT + ct * 32 + b;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) R.w[dx] = ld_frag(wp + static_cast<size_t>(dx) * CQI * COUT);
+    };
+    auto compute = [&](const StepRegs<NX>& R) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) {
+                const int xo = x0 + i;
+                const int xi = xo + dx - 1;
+                if (xo >= BW || xi < 0 || xi >= BW) continue;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.w[dx].v[t], R.x[i + dx].v[t], acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    StepRegs<NX> Ra, Rb;
+    load(0, Ra);
+    for (int s = 0; s < nsteps; s += 2) {
+        if (s + 1 < nsteps) load(s + 1, Rb);
+        compute(Ra);
+        if (s + 2 < nsteps) load(s + 2, Ra);
+        if (s + 1 < nsteps) compute(Rb);
+    }
+
+    // epilogue: D row = cout (reg&3) + 8*(reg>>2) + 4*half, col = board b
+    const int CQO = COUT >> 2;
+#pragma unroll
+    for (int i = 0; i < XT; ++i) {
+        const int xo = x0 + i;
+        if (xo >= BW) continue;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int cqo = ct * 8 + 2 * rg + half;
+            const float4 sc = scale[cqo];
+            const float4 sh = shift[cqo];
+            const size_t o = ((in_grp + static_cast<size_t>(y) * BW + xo) * CQO + cqo) * kGroup + b;
+            float4 v;
+            v.x = fmaf(acc[i][4 * rg + 0], sc.x, sh.x);
+            v.y = fmaf(acc[i][4 * rg + 1], sc.y, sh.y);
+            v.z = fmaf(acc[i][4 * rg + 2], sc.z, sh.z);
+            v.w = fmaf(acc[i][4 * rg + 3], sc.w, sh.w);
+            if (RES) {
+                const float4 rr = res[o];
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            out[o] = v;
+        }
+    }
+}
+
+// 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
+// hbuf[board][3][A]: channel 0,1 = policy head, 2 = value head.
+__global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in, const float* __restrict__ w3,
+                                                   const float* __restrict__ sc3, const float* __restrict__ sh3,
+                                                   float* __restrict__ hbuf, int A, int CQ) {
+    extern __shared__ float s_w[];  // [3][planes]
+    const int planes = CQ * 4;
+    for (int i = threadIdx.x; i < 3 * planes; i += blockDim.x) s_w[i] = w3[i];
+    __syncthreads();
+    const int nchunk = (A + 7) / 8;
+    const int grp = blockIdx.x / nchunk;
+    const int pos = (blockIdx.x - grp * nchunk) * 8 + (threadIdx.x >> 5);
+    const int b = threadIdx.x & 31;
+    if (pos >= A) return;
+    const float4* xp = in + ((static_cast<size_t>(grp) * A + pos) * CQ) * kGroup + b;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int cq = 0; cq < CQ; ++cq) {
+        const float4 x = xp[static_cast<size_t>(cq) * kGroup];
+        const float* w0 = s_w + 4 * cq;
+        const float* w1 = s_w + planes + 4 * cq;
+        const float* w2 = s_w + 2 * planes + 4 * cq;
+        a0 = fmaf(x.x, w0[0], a0); a0 = fmaf(x.y, w0[1], a0); a0 = fmaf(x.z, w0[2], a0); a0 = fmaf(x.w, w0[3], a0);
+        a1 = fmaf(x.x, w1[0], a1); a1 = fmaf(x.y, w1[1], a1); a1 = fmaf(x.z, w1[2], a1); a1 = fmaf(x.w, w1[3], a1);
+        a2 = fmaf(x.x, w2[0], a2); a2 = fmaf(x.y, w2[1], a2); a2 = fmaf(x.z, w2[2], a2); a2 = fmaf(x.w, w2[3], a2);
+    }
+    const size_t board = static_cast<size_t>(grp) * kGroup + b;
+    float* h = hbuf + board * 3 * A + pos;
+    h[0] = fmaxf(fmaf(a0, sc3[0], sh3[0]), 0.f);
+    h[A] = fmaxf(fmaf(a1, sc3[1], sh3[1]), 0.f);
+    h[2 * A] = fmaxf(fmaf(a2, sc3[2], sh3[2]), 0.f);
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wid] = v;
+    __syncthreads();
+    float r = s_red[0];
+    for (int i = 1; i < static_cast<int>(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, s_red[i]) : r + s_red[i];
+    return r;
+}
+
+// policy_fc + softmax (model.py:40-50), value_fc1 + ReLU + value_fc2 + tanh (model.py:59-73).
+// One block per board. The flatten order before the FCs is NCHW (c*A + cell), which is hbuf's.
+__global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf, const float* __restrict__ wp_t,
+                                                 const float* __restrict__ bp, const float* __restrict__ w1_t,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ policy,
+                                                 float* __restrict__ value, int A, int planes) {
+    extern __shared__ float s_h[];  // [3A] inputs, [A] logits, [planes] hidden, [8] reduce
+    float* s_logit = s_h + 3 * A;
+    float* s_hid = s_logit + A;
+    float* s_red = s_hid + planes;
+    const size_t board = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * A; i += blockDim.x) s_h[i] = hbuf[board * 3 * A + i];
+    __syncthreads();
+    float lmax = -3.0e38f;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        float acc = bp[a];
+        for (int j = 0; j < 2 * A; ++j) acc = fmaf(wp_t[static_cast<size_t>(j) * A + a], s_h[j], acc);
+        s_logit[a] = acc;
+        lmax = fmaxf(lmax, acc);
+    }
+    lmax = block_reduce(lmax, s_red, true);
+    float lsum = 0.f;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        const float ex = expf(s_logit[a] - lmax);
+        s_logit[a] = ex;
+        lsum += ex;
+    }
+    lsum = block_reduce(lsum, s_red, false);
+    for (int a = threadIdx.x; a < A; a += blockDim.x) policy[board * A + a] = s_logit[a] / lsum;
+    // value head
+    for (int o = threadIdx.x; o < planes; o += blockDim.x) {
+        float acc = b1[o];
+        for (int j = 0; j < A; ++j) acc = fmaf(w1_t[static_cast<size_t>(j) * planes + o], s_h[2 * A + j], acc);
+        s_hid[o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int o = threadIdx.x; o < planes; o += blockDim.x) part = fmaf(w2[o], s_hid[o], part);
+    part = block_reduce(part, s_red, false);
+    if (threadIdx.x == 0) value[board] = tanhf(part + b2[0]);
+}
+
+// [batch][C][A] float32 (Agent.model's input layout, agents.py:175) -> interleaved batch
+__global__ void k_nchw_to_il(const float* __restrict__ x, float4* __restrict__ il, int batch, int C, int A,
+                             int nchq, int boards_padded) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t total = static_cast<size_t>(boards_padded) * A;
+    if (i >= total) return;
+    const int board = static_cast<int>(i / A), cell = static_cast<int>(i - static_cast<size_t>(board) * A);
+    const size_t grp = board >> 5;
+    const int b = board & 31;
+    for (int cq = 0; cq < nchq; ++cq) {
+        float v[4];
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            v[k] = (board < batch && c < C) ? x[(static_cast<size_t>(board) * C + c) * A + cell] : 0.f;
+        }
+        il[((grp * A + cell) * nchq + cq) * kGroup + b] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+}  // namespace ao
+
+// ==============================================================================================
+// host side
+// ==============================================================================================
+struct ao_net {
+    int nb = 0, C = 0, planes = 0, B = 0, A = 0, device = 0;
+    int nchq = 0, CQ = 0;
+    bool finalized = false;
+    std::string err;
+    std::map<std::string, std::vector<float>> params;
+    std::vector<void*> allocs;
+    // device parameters
+    std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]
+    float *head_w3 = nullptr, *head_sc3 = nullptr, *head_sh3 = nullptr;
+    float *wp_t = nullptr, *bp = nullptr, *w1_t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+    // workspace
+    int ws_groups = 0;
+    float *act_x = nullptr, *act_t = nullptr, *hbuf = nullptr, *il_in = nullptr;
+    // timing of the trunk 3x3 convolutions
+    bool timing = false;
+    static constexpr int kRing = 512;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ring_head = 0, ring_count = 0;
+    double ms_total = 0.0;
+    int64_t launches = 0;
+
+    int fail(const std::string& m) { err = m; return 1; }
+};
+
+#define NET_HIP(n, call)                                                                      \
+    do {                                                                                      \
+        hipError_t st_ = (call);                                                              \
+        if (st_ != hipSuccess)                                                                \
+            return (n)->fail(std::string(#call) + ": " + hipGetErrorString(st_));             \
+    } while (0)
+
+static thread_local std::string g_net_create_error;
+
+template <typename T>
+static int net_alloc(ao_net* n, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t st = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
+    if (st != hipSuccess) return n->fail(std::string("hipMalloc: ") + hipGetErrorString(st));
+    n->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return 0;
+}
+
+static int upload(ao_net* n, float** dst, const std::vector<float>& src) {
+    if (net_alloc(n, dst, src.size())) return 1;
+    NET_HIP(n, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void harvest(ao_net* n, int count) {
+    for (int i = 0; i < count; ++i) {
+        const int idx = (n->ring_head - n->ring_count + ao_net::kRing * 2) % ao_net::kRing;
+        hipEventSynchronize(n->ev1[idx]);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, n->ev0[idx], n->ev1[idx]) == hipSuccess) {
+            n->ms_total += ms;
+            n->launches += 1;
+        }
+        --n->ring_count;
+    }
+}
+
+namespace ao {
+
+int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why) {
+    if (!n->finalized) { *why = "network not finalized"; return 1; }
+    if (n->B != board || n->C != inplanes) { *why = "network board/inplanes differ from the engine's"; return 1; }
+    if (n->device != device) { *why = "network lives on another device"; return 1; }
+    return 0;
+}
+
+template <int BW>
+static void launch_conv(ao_net* n, int layer, const float* in, int cqi, const float* res, float* out,
+                        int groups, hipStream_t s) {
+    constexpr int XT = (BW <= 9) ? BW : 8;  // cells per workgroup (accumulator tiles per wave)
+    constexpr int NXT = (BW + XT - 1) / XT;
+    const int nblk = groups * BW * NXT;
+    const dim3 grid(nblk), block(64 * (n->planes / 32));
+    const bool timed = n->timing && layer > 0;
+    int idx = 0;
+    if (timed) {
+        if (n->ring_count == ao_net::kRing) harvest(n, ao_net::kRing / 2);
+        idx = n->ring_head;
+        hipEventRecord(n->ev0[idx], s);
+    }
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    const float4* w4 = reinterpret_cast<const float4*>(n->conv_w[layer]);
+    const float4* sc4 = reinterpret_cast<const float4*>(n->conv_sc[layer]);
+    const float4* sh4 = reinterpret_cast<const float4*>(n->conv_sh[layer]);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    if (res)
+        hipLaunchKernelGGL((k_conv3x3<BW, XT, true>), grid, block, 0, s, in4, w4, sc4, sh4,
+                           reinterpret_cast<const float4*>(res), out4, cqi, n->planes, nblk);
+    else
+        hipLaunchKernelGGL((k_conv3x3<BW, XT, false>), grid, block, 0, s, in4, w4, sc4, sh4,
+                           static_cast<const float4*>(nullptr), out4, cqi, n->planes, nblk);
+    if (timed) {
+        hipEventRecord(n->ev1[idx], s);
+        n->ring_head = (n->ring_head + 1) % ao_net::kRing;
+        ++n->ring_count;
+    }
+}
+
+static int ensure_workspace(ao_net* n, int groups) {
+    if (groups <= n->ws_groups) return 0;
+    // grow-only; old buffers stay in n->allocs until destroy (forward sizes rarely change)
+    const size_t act = static_cast<size_t>(groups) * n->A * n->planes * kGroup;
+    if (net_alloc(n, &n->act_x, act) || net_alloc(n, &n->act_t, act) ||
+        net_alloc(n, &n->hbuf, static_cast<size_t>(groups) * kGroup * 3 * n->A) ||
+        net_alloc(n, &n->il_in, static_cast<size_t>(groups) * n->A * n->nchq * 4 * kGroup))
+        return 1;
+    n->ws_groups = groups;
+    return 0;
+}
+
+int net_forward_il(ao_net* n, const float* in_il, int groups, float* policy, float* value, hipStream_t s) {
+    if (!n->finalized) return n->fail("ao_net_finalize has not been called");
+    NET_HIP(n, hipSetDevice(n->device));
+    if (ensure_workspace(n, groups)) return 1;
+    auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
+        switch (n->B) {
+#define AO_BW_CASE(W) case W: launch_conv<W>(n, layer, in, cqi, res, out, groups, s); break;
+            AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+            AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+        }
+    };
+    conv(0, in_il, n->nchq, nullptr, n->act_x);                       // conv1 + bn1 + relu
+    for (int i = 0; i < n->nb; ++i) {                                  // ResBlock (model.py:22-31)
+        conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
+        conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
+    }
+    const int nchunk = (n->A + 7) / 8;
+    hipLaunchKernelGGL(k_head_conv, dim3(groups * nchunk), dim3(256), 3 * n->planes * sizeof(float), s,
+                       reinterpret_cast<const float4*>(n->act_x), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf,
+                       n->A, n->CQ);
+    const size_t lds = (static_cast<size_t>(4) * n->A + n->planes + 8) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fc, dim3(groups * kGroup), dim3(256), lds, s, n->hbuf, n->wp_t, n->bp, n->w1_t,
+                       n->b1, n->w2, n->b2, policy, value, n->A, n->planes);
+    NET_HIP(n, hipGetLastError());
+    return 0;
+}
+
+}  // namespace ao
+
+extern "C" {
+
+const char* ao_net_last_error(const ao_net* n) { return n ? n->err.c_str() : g_net_create_error.c_str(); }
+
+int ao_net_create(int n_block, int inplanes, int planes, int board, int device, ao_net** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    auto bad = [&](const char* m) { g_net_create_error = m; return 1; };
+    if (n_block < 0 || n_block > 64) return bad("n_block out of range");
+    if (inplanes < 1 || inplanes > 12) return bad("inplanes must be in 1..12");
+    if (planes < 32 || planes > 128 || planes % 32) return bad("planes must be 32, 64, 96 or 128");
+    if (board < 3 || board > ao::kMaxBoard) return bad("board must be in 3..15");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad("no HIP device available");
+    if (device < 0 || device >= ndev) return bad("device ordinal out of range");
+    ao_net* n = new ao_net();
+    n->nb = n_block; n->C = inplanes; n->planes = planes; n->B = board; n->A = board * board;
+    n->device = device; n->nchq = (inplanes + 3) / 4;
+    if (n->nchq & 1) n->nchq += 1;  // the conv kernel consumes channel quads in pairs
+    n->CQ = planes / 4;
+    *out = n;
+    return 0;
+}
+
+void ao_net_destroy(ao_net* n) {
+    if (!n) return;
+    hipSetDevice(n->device);
+    hipDeviceSynchronize();
+    for (void* p : n->allocs) hipFree(p);
+    for (auto e : n->ev0) hipEventDestroy(e);
+    for (auto e : n->ev1) hipEventDestroy(e);
+    delete n;
+}
+
+int ao_net_set_param(ao_net* n, const char* name, const float* data, int64_t numel) {
+    if (!name || (!data && numel > 0) || numel < 0) return n->fail("bad argument");
+    n->params[name] = std::vector<float>(data, data + numel);
+    n->finalized = false;
+    return 0;
+}
+
+static int get_param(ao_net* n, const std::string& name, size_t numel, const std::vector<float>** out) {
+    auto it = n->params.find(name);
+    if (it == n->params.end()) return n->fail("missing parameter " + name);
+    if (it->second.size() != numel)
+        return n->fail("parameter " + name + " has " + std::to_string(it->second.size()) + " elements, expected " +
+                       std::to_string(numel));
+    *out = &it->second;
+    return 0;
+}
+
+// BatchNorm2d in eval mode (eps 1e-5): y = x*scale + shift
+static int fold_bn(ao_net* n, const std::string& prefix, int c, std::vector<float>* sc, std::vector<float>* sh) {
+    const std::vector<float>*w, *b, *m, *v;
+    if (get_param(n, prefix + ".weight", c, &w) || get_param(n, prefix + ".bias", c, &b) ||
+        get_param(n, prefix + ".running_mean", c, &m) || get_param(n, prefix + ".running_var", c, &v))
+        return 1;
+    sc->resize(c); sh->resize(c);
+    for (int i = 0; i < c; ++i) {
+        const double s = static_cast<double>((*w)[i]) / std::sqrt(static_cast<double>((*v)[i]) + 1e-5);
+        (*sc)[i] = static_cast<float>(s);
+        (*sh)[i] = static_cast<float>(static_cast<double>((*b)[i]) - static_cast<double>((*m)[i]) * s);
+    }
+    return 0;
+}
+
+int ao_net_finalize(ao_net* n) {
+    NET_HIP(n, hipSetDevice(n->device));
+    for (void* p : n->allocs) hipFree(p);
+    n->allocs.clear();
+    n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
+    n->ws_groups = 0;
+    const int P = n->planes, A = n->A;
+    auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
+        const std::vector<float>* w;
+        if (get_param(n, wname, static_cast<size_t>(P) * cin * 9, &w)) return 1;
+        // OIHW -> [tap][cq][cout][4]
+        std::vector<float> packed(static_cast<size_t>(9) * cqi * P * 4, 0.f);
+        for (int co = 0; co < P; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t)
+                    packed[((static_cast<size_t>(t) * cqi + (ci >> 2)) * P + co) * 4 + (ci & 3)] =
+                        (*w)[(static_cast<size_t>(co) * cin + ci) * 9 + t];
+        std::vector<float> sc, sh;
+        if (fold_bn(n, bnname, P, &sc, &sh)) return 1;
+        float *dw, *dsc, *dsh;
+        if (upload(n, &dw, packed) || upload(n, &dsc, sc) || upload(n, &dsh, sh)) return 1;
+        n->conv_w.push_back(dw); n->conv_sc.push_back(dsc); n->conv_sh.push_back(dsh);
+        return 0;
+    };
+    if (add_conv("conv1.weight", "bn1", n->C, n->nchq)) return 1;
+    for (int i = 0; i < n->nb; ++i) {
+        const std::string pre = "layers." + std::to_string(i);
+        if (add_conv(pre + ".conv1.weight", pre + ".bn1", P, n->CQ)) return 1;
+        if (add_conv(pre + ".conv2.weight", pre + ".bn2", P, n->CQ)) return 1;
+    }
+    // heads
+    const std::vector<float>*pw, *vw, *fcw, *fcb, *f1w, *f1b, *f2w, *f2b;
+    if (get_param(n, "policy_head.policy_head.weight", 2 * P, &pw) ||
+        get_param(n, "value_head.value_head.weight", P, &vw) ||
+        get_param(n, "policy_head.policy_fc.weight", static_cast<size_t>(A) * 2 * A, &fcw) ||
+        get_param(n, "policy_head.policy_fc.bias", A, &fcb) ||
+        get_param(n, "value_head.value_fc1.weight", static_cast<size_t>(P) * A, &f1w) ||
+        get_param(n, "value_head.value_fc1.bias", P, &f1b) ||
+        get_param(n, "value_head.value_fc2.weight", P, &f2w) || get_param(n, "value_head.value_fc2.bias", 1, &f2b))
+        return 1;
+    std::vector<float> w3(static_cast<size_t>(3) * P);
+    std::copy(pw->begin(), pw->end(), w3.begin());
+    std::copy(vw->begin(), vw->end(), w3.begin() + 2 * P);
+    std::vector<float> psc, psh, vsc, vsh;
+    if (fold_bn(n, "policy_head.policy_bn", 2, &psc, &psh) || fold_bn(n, "value_head.value_bn", 1, &vsc, &vsh))
+        return 1;
+    std::vector<float> sc3 = {psc[0], psc[1], vsc[0]}, sh3 = {psh[0], psh[1], vsh[0]};
+    std::vector<float> wp_t(static_cast<size_t>(2) * A * A), w1_t(static_cast<size_t>(A) * P);
+    for (int a = 0; a < A; ++a)
+        for (int j = 0; j < 2 * A; ++j) wp_t[static_cast<size_t>(j) * A + a] = (*fcw)[static_cast<size_t>(a) * 2 * A + j];
+    for (int o = 0; o < P; ++o)
+        for (int j = 0; j < A; ++j) w1_t[static_cast<size_t>(j) * P + o] = (*f1w)[static_cast<size_t>(o) * A + j];
+    if (upload(n, &n->head_w3, w3) || upload(n, &n->head_sc3, sc3) || upload(n, &n->head_sh3, sh3) ||
+        upload(n, &n->wp_t, wp_t) || upload(n, &n->bp, *fcb) || upload(n, &n->w1_t, w1_t) ||
+        upload(n, &n->b1, *f1b) || upload(n, &n->w2, *f2w) || upload(n, &n->b2, *f2b))
+        return 1;
+    NET_HIP(n, hipDeviceSynchronize());
+    n->finalized = true;
+    return 0;
+}
+
+int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* dev_policy, float* dev_value,
+                   void* stream) {
+    if (!n->finalized) return n->fail("ao_net_finalize has not been called");
+    if (batch < 1) return n->fail("batch must be >= 1");
+    NET_HIP(n, hipSetDevice(n->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int groups = (batch + ao::kGroup - 1) / ao::kGroup;
+    if (ao::ensure_workspace(n, groups)) return 1;
+    const int boards = groups * ao::kGroup;
+    // policy/value rows of the padding boards are written too: run the heads into scratch when
+    // the batch is not a multiple of 32
+    float *pol = dev_policy, *val = dev_value;
+    float *tmp_p = nullptr, *tmp_v = nullptr;
+    if (boards != batch) {
+        NET_HIP(n, hipMalloc(reinterpret_cast<void**>(&tmp_p), sizeof(float) * boards * n->A));
+        NET_HIP(n, hipMalloc(reinterpret_cast<void**>(&tmp_v), sizeof(float) * boards));
+        pol = tmp_p; val = tmp_v;
+    }
+    const size_t total = static_cast<size_t>(boards) * n->A;
+    hipLaunchKernelGGL(ao::k_nchw_to_il, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
+                       dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, n->nchq, boards);
+    int rc = ao::net_forward_il(n, n->il_in, groups, pol, val, s);
+    if (!rc && boards != batch) {
+        hipMemcpyAsync(dev_policy, tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(dev_value, tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s);
+        hipStreamSynchronize(s);
+    }
+    if (tmp_p) hipFree(tmp_p);
+    if (tmp_v) hipFree(tmp_v);
+    return rc;
+}
+
+int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launches) {
+    NET_HIP(n, hipSetDevice(n->device));
+    if (n->ev0.empty() && enable) {
+        n->ev0.resize(ao_net::kRing);
+        n->ev1.resize(ao_net::kRing);
+        for (int i = 0; i < ao_net::kRing; ++i) {
+            NET_HIP(n, hipEventCreate(&n->ev0[i]));
+            NET_HIP(n, hipEventCreate(&n->ev1[i]));
+        }
+    }
+    harvest(n, n->ring_count);
+    if (ms_total) *ms_total = n->ms_total;
+    if (launches) *launches = n->launches;
+    n->ms_total = 0.0;
+    n->launches = 0;
+    n->timing = enable != 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Python handles over the C ABI: `Engine` (G concurrent games) and `Net` (PVNet weights).
+
+Thin by design: argument marshalling and error propagation only. Tensors are exchanged as raw
+device pointers (torch.Tensor.data_ptr()); no torch types cross the boundary.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AO_ROOT_EXPANDED, AO_ROOT_FRESH, AO_ROOT_UNEXPANDED  # noqa: F401
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+class Net:
+    """model.PVNet(n_block, inplanes, planes, board_size) in eval() mode, on the MI355X."""
+
+    def __init__(self, n_block, inplanes, planes, board_size, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        if self._L.ao_net_create(n_block, inplanes, planes, board_size, device, C.byref(h)):
+            raise EngineError("ao_net_create: " + self._L.ao_net_last_error(None).decode())
+        self._h = h
+        self.n_block, self.inplanes, self.planes, self.board_size = n_block, inplanes, planes, board_size
+        self.device = device
+        self.A = board_size * board_size
+
+    def _check(self, rc, what):
+        if rc:
+            raise EngineError("%s: %s" % (what, self._L.ao_net_last_error(self._h).decode()))
+
+    def load_state_dict(self, state_dict):
+        """state_dict: name -> array-like (numpy or torch tensor), reference key names."""
+        for name, val in state_dict.items():
+            if hasattr(val, "detach"):
+                val = val.detach().cpu().numpy()
+            arr = np.ascontiguousarray(np.asarray(val), dtype=np.float32).reshape(-1)
+            self._check(self._L.ao_net_set_param(self._h, name.encode(), _ptr(arr, C.c_float), arr.size),
+                        "ao_net_set_param(%s)" % name)
+        self._check(self._L.ao_net_finalize(self._h), "ao_net_finalize")
+        return self
+
+    def forward_ptr(self, planes_ptr, batch, policy_ptr, value_ptr, stream=None):
+        self._check(self._L.ao_net_forward(self._h, planes_ptr, batch, policy_ptr, value_ptr, stream),
+                    "ao_net_forward")
+
+    def __call__(self, x):
+        """x: torch.cuda float32 [batch, C, B, B] -> (policy [batch, A], value [batch]) tensors."""
+        import torch
+        x = x.contiguous().float()
+        batch = x.shape[0]
+        pol = torch.empty((batch, self.A), dtype=torch.float32, device=x.device)
+        val = torch.empty((batch,), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        self.forward_ptr(x.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), stream)
+        return pol, val
+
+    def conv_timing(self, enable=True):
+        """Returns (total ms, launches) of the trunk 3x3 conv kernel since the last call."""
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self._L.ao_net_conv_timing(self._h, 1 if enable else 0, C.byref(ms), C.byref(cnt)),
+                    "ao_net_conv_timing")
+        return ms.value, cnt.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ao_net_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """G concurrent games: SoA search trees in HBM + the tree kernels (see include/omok_hip.h)."""
+
+    def __init__(self, board_size, num_mcts, inplanes=5, games=1, noise=True, device=0, node_cap=0,
+                 c_puct=0.0, alpha=0.0, win_mark=0):
+        self._L = _lib.load()
+        cfg = _lib.AoConfig(board=board_size, win_mark=win_mark, sims=num_mcts, inplanes=inplanes,
+                            games=games, noise=1 if noise else 0, node_cap=node_cap, device=device,
+                            c_puct=c_puct, alpha=alpha)
+        h = C.c_void_p()
+        if self._L.ao_create(C.byref(cfg), C.byref(h)):
+            raise EngineError("ao_create: " + self._L.ao_last_error(None).decode())
+        self._h = h
+        self.board_size, self.num_mcts, self.inplanes, self.G = board_size, num_mcts, inplanes, games
+        self.A = board_size * board_size
+        self.device = device
+
+    def _check(self, rc, what):
+        if rc:
+            raise EngineError("%s: %s" % (what, self._L.ao_last_error(self._h).decode()))
+
+    # -- rng
+    def seed(self, game, seed):
+        self._check(self._L.ao_seed(self._h, game, seed & 0xFFFFFFFF), "ao_seed")
+
+    def seed_all(self, seeds):
+        s = np.ascontiguousarray(seeds, np.uint32)
+        assert s.size == self.G
+        self._check(self._L.ao_seed_all(self._h, _ptr(s, C.c_uint32)), "ao_seed_all")
+
+    def get_rng_state(self, game):
+        mt = np.zeros(624, np.uint32)
+        pos, hg, gs = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        self._check(self._L.ao_get_rng_state(self._h, game, _ptr(mt, C.c_uint32), C.byref(pos), C.byref(hg),
+                                             C.byref(gs)), "ao_get_rng_state")
+        return mt, pos.value, hg.value, gs.value
+
+    def set_rng_state(self, game, mt, pos, has_gauss=0, gauss=0.0):
+        mt = np.ascontiguousarray(mt, np.uint32)
+        self._check(self._L.ao_set_rng_state(self._h, game, _ptr(mt, C.c_uint32), int(pos), int(has_gauss),
+                                             float(gauss)), "ao_set_rng_state")
+
+    # -- state
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self._L.ao_reset(self._h, _ptr(m, C.c_uint8)), "ao_reset")
+
+    def set_root(self, game, moves):
+        mv = np.ascontiguousarray(list(moves), np.int32)
+        st = C.c_int32(0)
+        self._check(self._L.ao_set_root(self._h, game, _ptr(mv, C.c_int32), mv.size, C.byref(st)), "ao_set_root")
+        return st.value
+
+    def get_moves(self, game):
+        mv = np.zeros(self.A + 1, np.int32)
+        n = C.c_int32(0)
+        self._check(self._L.ao_get_moves(self._h, game, _ptr(mv, C.c_int32), C.byref(n)), "ao_get_moves")
+        return mv[:n.value].tolist()
+
+    # -- stepwise move
+    def set_stream(self, stream_ptr):
+        self._check(self._L.ao_set_stream(self._h, stream_ptr), "ao_set_stream")
+
+    def sync(self):
+        self._check(self._L.ao_sync(self._h), "ao_sync")
+
+    def begin_move(self, active=None):
+        a = None if active is None else np.ascontiguousarray(active, np.uint8)
+        self._check(self._L.ao_begin_move(self._h, _ptr(a, C.c_uint8)), "ao_begin_move")
+
+    def sims_left(self):
+        return self._L.ao_sims_left(self._h)
+
+    def collect_leaves(self, planes_ptr=None):
+        self._check(self._L.ao_collect_leaves(self._h, planes_ptr), "ao_collect_leaves")
+
+    def apply_evals(self, policy_ptr, value_ptr):
+        self._check(self._L.ao_apply_evals(self._h, policy_ptr, value_ptr), "ao_apply_evals")
+
+    def _outs(self):
+        return tuple(np.zeros((self.G, self.A), np.float64) for _ in range(3))
+
+    def end_move(self, tau=None):
+        """Returns (pi, visit, policy), float64 [G, A] each."""
+        t = None if tau is None else np.ascontiguousarray(np.broadcast_to(tau, (self.G,)), np.int8)
+        pi, vis, pol = self._outs()
+        self._check(self._L.ao_end_move(self._h, _ptr(t, C.c_int8), _ptr(pi, C.c_double), _ptr(vis, C.c_double),
+                                        _ptr(pol, C.c_double)), "ao_end_move")
+        return pi, vis, pol
+
+    def play(self):
+        """utils.get_action + env.step + re-root. Returns (action[G], win_index[G])."""
+        act = np.zeros(self.G, np.int32)
+        win = np.zeros(self.G, np.int32)
+        self._check(self._L.ao_play(self._h, _ptr(act, C.c_int32), _ptr(win, C.c_int32)), "ao_play")
+        return act, win
+
+    # -- fused move with the native network
+    def search(self, net, tau=None, active=None):
+        t = None if tau is None else np.ascontiguousarray(np.broadcast_to(tau, (self.G,)), np.int8)
+        a = None if active is None else np.ascontiguousarray(active, np.uint8)
+        pi, vis, pol = self._outs()
+        self._check(self._L.ao_search(self._h, net._h, _ptr(a, C.c_uint8), _ptr(t, C.c_int8),
+                                      _ptr(pi, C.c_double), _ptr(vis, C.c_double), _ptr(pol, C.c_double)),
+                    "ao_search")
+        return pi, vis, pol
+
+    # -- introspection
+    def root_children(self, game):
+        A = self.A
+        act = np.zeros(A, np.int32)
+        n, w, q, p = (np.zeros(A) for _ in range(4))
+        cnt = C.c_int32(0)
+        self._check(self._L.ao_get_root_children(self._h, game, _ptr(act, C.c_int32), _ptr(n, C.c_double),
+                                                 _ptr(w, C.c_double), _ptr(q, C.c_double), _ptr(p, C.c_double),
+                                                 C.byref(cnt)), "ao_get_root_children")
+        k = cnt.value
+        return dict(action=act[:k].copy(), n=n[:k].copy(), w=w[:k].copy(), q=q[:k].copy(), p=p[:k].copy())
+
+    def tree_nodes(self, game):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._L.ao_tree_nodes(self._h, game, C.byref(a), C.byref(b)), "ao_tree_nodes")
+        return a.value, b.value
+
+    def search_stats(self):
+        v = [C.c_int64(0) for _ in range(4)]
+        self._check(self._L.ao_search_stats(self._h, *[C.byref(x) for x in v]), "ao_search_stats")
+        return dict(levels=v[0].value, ties=v[1].value, terminal=v[2].value, evaluated=v[3].value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ao_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -55,6 +55,10 @@ void ao_destroy(ao_engine *e);
 const char *ao_last_error(const ao_engine *e);   /* e may be NULL: error of the failed ao_create */
 void *ao_stream(ao_engine *e);                   /* hipStream_t all engine work is queued on     */
 int  ao_sync(ao_engine *e);                      /* hipStreamSynchronize                          */
+/* Queue all further engine work on `stream` (a hipStream_t, e.g. torch's current stream) so an
+ * external evaluator running on that stream needs no extra synchronisation. NULL restores the
+ * engine's own stream. */
+int  ao_set_stream(ao_engine *e, void *stream);
 
 /* ---- per-game RNG ---- replaces np.random.seed / get_state / set_state (main.py:60).
  * ao_seed == np.random.seed(seed) for game g (MT19937 init_genrand, pos 624, no cached gauss). */

@@ -1,0 +1,115 @@
+"""-m gpu: the hand-written fp32 MFMA PVNet forward against (1) golden (p, v) produced by the
+reference's model.PVNet and (2) a torch fp32 reference, tolerance 1e-4 absolute on p and v
+(BASELINE.json north_star); then the fused search (ao_search) against the oracle."""
+import numpy as np
+import pytest
+
+import pvnet_weights
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _native(nb, C, planes, B, seed):
+    from alpha_omok_amd.engine import Net
+    net = Net(nb, C, planes, B, 0)
+    net.load_state_dict(pvnet_weights.make_state_dict(nb, C, planes, B, seed))
+    return net
+
+
+def test_golden_gv7_forward():
+    import torch
+    g = load_golden("gv7_pvnet_forward")
+    for i in range(int(g["count"])):
+        nb, B, planes, wseed = g["cfg%d" % i].tolist()
+        net = _native(nb, 5, planes, B, wseed)
+        x = torch.from_numpy(g["x%d" % i]).cuda()
+        p, v = net(x)
+        torch.cuda.synchronize()
+        dp = np.abs(p.cpu().numpy() - g["p%d" % i]).max()
+        dv = np.abs(v.cpu().numpy() - g["v%d" % i]).max()
+        assert dp < TOL and dv < TOL, (nb, B, planes, dp, dv)
+        assert abs(p.sum(dim=1).cpu().numpy() - 1).max() < 1e-5
+        net.close()
+
+
+@pytest.mark.parametrize("nb,B,planes,batch", [(4, 9, 128, 70), (10, 9, 128, 33), (2, 15, 128, 40),
+                                               (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64)])
+def test_forward_vs_torch_fp32(nb, B, planes, batch):
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    sd = pvnet_weights.make_state_dict(nb, 5, planes, B, 100 + nb)
+    ref = PVNet(nb, 5, planes, B)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ref.eval()
+    rs = np.random.RandomState(batch)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    x[:, 4] = (rs.rand(batch, 1, 1) < 0.5).astype(np.float32)
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x))
+    net = ref.to_native(0)
+    p, v = net(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    dp = np.abs(p.cpu().numpy() - rp.numpy()).max()
+    dv = np.abs(v.cpu().numpy() - rv.numpy()).max()
+    assert dp < TOL and dv < TOL, (dp, dv)
+    net.close()
+
+
+def test_fused_search_matches_stepwise_and_oracle(oracle):
+    """ao_search (select -> native PVNet -> expand on one stream) == the stepwise protocol fed by
+    the same network through ao_net_forward, and == the oracle replaying those (p, v)."""
+    import torch
+    from alpha_omok_amd.engine import Engine
+    from gpu_helpers import HostEvalRunner
+    B, S, G, plies = 9, 64, 33, 3
+    net = _native(2, 5, 64, B, 42)
+    seeds = [500 + g for g in range(G)]
+    e1 = Engine(B, S, 5, games=G, noise=True)
+    e2 = Engine(B, S, 5, games=G, noise=True)
+    e1.seed_all(seeds)
+    e2.seed_all(seeds)
+    run = HostEvalRunner(e2)
+    rec = [[] for _ in range(G)]
+    for t in range(plies):
+        tau = np.full(G, 1 if t < 2 else 0, np.int8)
+        pi1, vis1, pol1 = e1.search(net, tau=tau)
+        # stepwise: evaluate the NCHW planes with the same network, record what each game saw
+        e2.begin_move()
+        while e2.sims_left() > 0:
+            e2.collect_leaves(run.planes.data_ptr())
+            e2.sync()
+            p, v = net(run.planes)
+            torch.cuda.synchronize()
+            hp, hv = p.cpu().numpy(), v.cpu().numpy()
+            for g in range(G):
+                rec[g].append((hp[g].copy(), hv[g].copy()))
+            e2.apply_evals(p.data_ptr(), v.data_ptr())
+        pi2, vis2, pol2 = e2.end_move(tau)
+        np.testing.assert_array_equal(vis1, vis2)
+        np.testing.assert_array_equal(pol1, pol2)
+        np.testing.assert_array_equal(pi1, pi2)
+        a1, w1 = e1.play()
+        a2, w2 = e2.play()
+        np.testing.assert_array_equal(a1, a2)
+        np.testing.assert_array_equal(w1, w2)
+        if t == 0:
+            first_vis, first_act = vis1.copy(), a1.copy()
+    # oracle replay of game 0 and game G-1, first ply (401 recorded evaluations each)
+    for g in (0, G - 1):
+        cur = [0]
+
+        def replay(moves, planes, sim, g=g, cur=cur):
+            i = cur[0]
+            cur[0] += 1
+            return rec[g][i]
+
+        ag = oracle.Agent(B, S, 5, noise=True, evaluator=replay)
+        ag.seed(seeds[g])
+        opi, ovis, opol = ag.get_pi((0,), 1)
+        np.testing.assert_array_equal(first_vis[g], ovis)
+        assert first_act[g] == ag.rng.choice_p(opi)
+    e1.close()
+    e2.close()
+    net.close()

@@ -1,0 +1,187 @@
+"""-m gpu: the HIP tree kernels (through the C ABI) against the CPU oracle and against the golden
+vectors captured from the reference. Bar: bit-exact visit counts, priors, w/q, chosen moves and
+MT19937 stream position (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from gpu_helpers import HostEvalRunner, children_by_action
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(*a, **k):
+    from alpha_omok_amd.engine import Engine
+    return Engine(*a, **k)
+
+
+def _compare_move(eng, g, ag, root, pi, vis, pol, tag):
+    opi, ovis, opol = ag
+    np.testing.assert_array_equal(vis[g], ovis, err_msg="visit " + tag)
+    np.testing.assert_array_equal(pol[g], opol, err_msg="policy " + tag)
+    np.testing.assert_array_equal(pi[g], opi, err_msg="pi " + tag)
+
+
+@pytest.mark.parametrize("board,sims,mode,plies,tau_thres", [
+    (9, 400, 0, 3, 6), (9, 400, 2, 3, 6), (9, 120, 1, 12, 4), (3, 50, 0, 9, 2), (3, 50, 1, 9, 0),
+    (15, 80, 2, 4, 6), (15, 60, 1, 5, 2), (5, 40, 0, 25, 3)])
+def test_multi_game_parity_with_oracle(oracle, board, sims, mode, plies, tau_thres):
+    """G games advance in lock-step on the GPU; every game must reproduce the oracle's
+    sequential search move by move (stub evaluator = exact arithmetic, so p/v are identical)."""
+    G = 6
+    eng = _engine(board, sims, 5, games=G, noise=True)
+    run = HostEvalRunner(eng)
+    seeds = [1000 + 17 * g for g in range(G)]
+    eng.seed_all(seeds)
+    agents = [oracle.Agent(board, sims, 5, noise=True, evaluator="stub%d" % mode) for _ in range(G)]
+    for g in range(G):
+        agents[g].seed(seeds[g])
+    roots = [(0,) for _ in range(G)]
+    alive = np.ones(G, np.uint8)
+    wm = 3 if board == 3 else 5
+
+    def ev(g, sim, planes):
+        return oracle.stub_eval(planes, mode)
+
+    for t in range(plies):
+        if not alive.any():
+            break
+        tau = np.array([1 if t < tau_thres else 0] * G, np.int8)
+        pi, vis, pol = run.move(ev, tau=tau, active=alive)
+        act, win = eng.play()
+        for g in range(G):
+            if not alive[g]:
+                continue
+            tag = "board %d game %d ply %d" % (board, g, t)
+            o = agents[g].get_pi(roots[g], int(tau[g]))
+            _compare_move(eng, g, o, roots[g], pi, vis, pol, tag)
+            oa = agents[g].rng.choice_p(o[0])
+            assert act[g] == oa, tag
+            roots[g] = roots[g] + (int(oa),)
+            mt, pos, _, _ = eng.get_rng_state(g)
+            assert pos == agents[g].rng.pos, tag
+            np.testing.assert_array_equal(mt, agents[g].rng.state_words(), err_msg="mt " + tag)
+            ow = oracle.check_win(oracle.get_board(list(roots[g])[1:], board), wm)
+            assert win[g] == ow, tag
+            if ow != 0:
+                alive[g] = 0
+    eng.close()
+
+
+def _run_golden_cases(oracle, g, evaluator_for_case, only=None):
+    meta = g["meta"].tolist()
+    for ci, (B, S, mode, seed, plies, tau_thres, noise, nrec, win) in enumerate(meta):
+        if only is not None and ci not in only:
+            continue
+        eng = _engine(B, S, 5, games=1, noise=bool(noise))
+        run = HostEvalRunner(eng)
+        eng.seed(0, seed)
+        ev = evaluator_for_case(ci, mode)
+        roots = g["c%d_root" % ci]
+        for t in range(nrec):
+            root = [int(x) for x in roots[t] if x >= 0]
+            st = eng.set_root(0, root)
+            assert st == (0 if t == 0 else 2)
+            tau = 1 if t < tau_thres else 0
+            pi, vis, pol = run.move(ev, tau=np.array([tau], np.int8))
+            tag = "case %d ply %d" % (ci, t)
+            np.testing.assert_array_equal(vis[0], g["c%d_visit" % ci][t], err_msg="visit " + tag)
+            np.testing.assert_array_equal(pol[0], g["c%d_policy" % ci][t], err_msg="policy " + tag)
+            np.testing.assert_array_equal(pi[0], g["c%d_pi" % ci][t], err_msg="pi " + tag)
+            ch = children_by_action(eng.root_children(0), B * B)
+            np.testing.assert_array_equal(ch["w"], g["c%d_w" % ci][t], err_msg="w " + tag)
+            np.testing.assert_array_equal(ch["q"], g["c%d_q" % ci][t], err_msg="q " + tag)
+            order = g["c%d_order" % ci][t]
+            assert ch["order"].tolist() == order[order >= 0].tolist(), tag
+            act, w = eng.play()
+            assert act[0] == int(g["c%d_action" % ci][t]), tag
+            mt, pos, _, _ = eng.get_rng_state(0)
+            assert pos == int(g["c%d_mt_pos" % ci][t]), tag
+            assert int(mt.astype(np.uint64).sum()) == int(g["c%d_mt_sum" % ci][t]), tag
+        eng.close()
+
+
+def test_golden_gv5_stub_tree(oracle):
+    """Direct check against the reference's own outputs (tests/golden/gv5_tree_stub.npz)."""
+    g = load_golden("gv5_tree_stub")
+    _run_golden_cases(oracle, g, lambda ci, mode: (lambda gi, sim, pl: oracle.stub_eval(pl, mode)))
+
+
+def test_golden_gv5_deep_roots(oracle):
+    """Roots with >= 63 stones on 9x9: child order follows CPython's set iteration."""
+    g = load_golden("gv5_tree_stub_deeproot")
+    _run_golden_cases(oracle, g, lambda ci, mode: (lambda gi, sim, pl: oracle.stub_eval(pl, mode)))
+
+
+def test_golden_gv6_real_net_replay():
+    """Search driven by the reference PVNet's recorded (p, v): same visits and moves."""
+    g = load_golden("gv6_tree_realnet")
+    ep, ev = g["eval_p"], g["eval_v"]
+    cursor = [0]
+
+    def replay(gi, sim, pl):
+        i = cursor[0]
+        cursor[0] += 1
+        return ep[i], ev[i]
+
+    # The reference evaluates the net on terminal leaves too; none occur in the first plies of a
+    # 9x9 game, so the recording is consumed one entry per simulation.
+    _run_golden_cases(None, g, lambda ci, mode: replay)
+    assert cursor[0] == len(ev)
+
+
+def test_planes_match_oracle(oracle):
+    """Leaf planes written by k_select == utils.get_state_pt of the leaf id."""
+    import torch
+    for board in (3, 9, 15):
+        eng = _engine(board, 30, 5, games=4, noise=True)
+        run = HostEvalRunner(eng)
+        eng.seed_all([5, 6, 7, 8])
+        seen = []
+
+        def ev(g, sim, planes):
+            seen.append(planes.copy())
+            # planes must be a valid get_state_pt output: rebuild the id from the planes' stones
+            return oracle.stub_eval(planes, 0)
+
+        run.move(ev)
+        # cross-check a handful against the oracle encoder through the stub's own hash: the
+        # multi-game parity test already proves equality indirectly; here check structure.
+        for pl in seen[:50]:
+            assert set(np.unique(pl)).issubset({0.0, 1.0})
+            assert pl[4].min() == pl[4].max()
+            own, opp = pl[2], pl[3]
+            assert (own * opp).sum() == 0
+            assert np.all(pl[0] <= pl[2]) and np.all(pl[1] <= pl[3])
+        eng.close()
+
+
+def test_set_root_semantics(oracle):
+    """ZeroAgent.get_pi with ids that jump two plies (eval_main's usage): known/unknown roots."""
+    B, S = 9, 60
+    eng = _engine(B, S, 5, games=1, noise=True)
+    run = HostEvalRunner(eng)
+    ag = oracle.Agent(B, S, 5, noise=True, evaluator="stub1")
+    eng.seed(0, 77)
+    ag.seed(77)
+
+    def ev(g, sim, pl):
+        return oracle.stub_eval(pl, 1)
+
+    root = (0,)
+    rs = np.random.RandomState(3)
+    for t in range(8):
+        st = eng.set_root(0, list(root)[1:])
+        pi, vis, pol = run.move(ev, tau=np.array([1], np.int8))
+        opi, ovis, opol = ag.get_pi(root, 1)
+        np.testing.assert_array_equal(vis[0], ovis, err_msg="ply %d status %d" % (t, st))
+        np.testing.assert_array_equal(pol[0], opol)
+        # our move: most visited; opponent's reply: a random legal cell (often unvisited)
+        a = int(np.argmax(ovis))
+        legal = [c for c in range(B * B) if c not in root[1:] and c != a]
+        b = int(legal[rs.randint(len(legal))])
+        root = root + (a, b)
+        # keep both RNG streams aligned (the engine's stream is per game)
+        mt, pos, hg, gs = eng.get_rng_state(0)
+        assert pos == ag.rng.pos
+    eng.close()

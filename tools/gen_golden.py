@@ -326,7 +326,7 @@ def gv7():
     idx = 0
     rng = np.random.RandomState(77)
     for (nb, B, planes, wseed) in ((1, 9, 32, 1), (2, 9, 128, 2), (4, 9, 128, 3), (2, 15, 64, 4),
-                                   (1, 3, 16, 5)):
+                                   (1, 3, 32, 5)):
         net = ref_model.PVNet(nb, 5, planes, B)
         sd = pvnet_weights.make_state_dict(nb, 5, planes, B, wseed)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
