@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play move-decisions/sec (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the largest single-GPU configuration; configs[3] is the same
+per GPU x 8): 9x9 Omok, 4096 concurrent self-play games per GPU, 400 MCTS simulations per move,
+one leaf per game per wave (leaf batch 4096), random-init 4-block/128-channel PVNet, fp32.
+A "step" = one move decision (400 simulations, 401 on a game's first move) for every game of the
+rank, then utils.get_action + env step + re-rooting; finished games are reset and re-seeded.
+Games shard across ranks with no data-path collective (weak scaling); value = all ranks' move
+decisions / max-over-ranks time.
+
+The JSON line also carries:
+  roofline      the dominant kernel (3x3 trunk convolution, fp32 MFMA): algorithmic FLOPs per
+                launch / average launch duration from HIP events on the launch stream, against
+                the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X.
+  cpu_baseline  the sequential per-game search (oracle/ C restatement of agents.py) with the
+                PVNet forward on PyTorch-CPU at batch 1 -- what main.self_play does -- timed on
+                this host for a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+
+
+def trunk_conv_flops(board, planes, boards):
+    """Algorithmic FLOPs of one 3x3 planes->planes convolution launch (2*MAC, zero padding counted
+    as in SURVEY.md 8(d): A*9*planes^2 MACs per board)."""
+    return 2.0 * board * board * 9 * planes * planes * boards
+
+
+def eval_flops(board, inplanes, planes, n_block):
+    """F_eval of SURVEY.md 8(d): convs + FCs of one PVNet evaluation."""
+    A = board * board
+    return 2.0 * (A * 9 * inplanes * planes + n_block * 2 * A * 9 * planes * planes + A * planes * 2 +
+                  2 * A * A + A * planes + A * planes + planes)
+
+
+def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
+    """Sequential reference-style search on the host CPU: oracle tree + torch-CPU net, batch 1."""
+    from alpha_omok_amd.pvnet import PVNet
+    from oracle import oracle_py as O
+    net = PVNet(n_block, 5, planes, board)
+    net.load_state_dict(state_dict)
+    net.eval()
+    cores = torch.get_num_threads()
+
+    def ev(moves, planes_, sim):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(planes_[None].copy()))
+        return p[0].numpy(), np.float32(v[0].item())
+
+    ag = O.Agent(board, sims, 5, noise=True, evaluator=ev)
+    ag.seed(0)
+    root = (0,)
+    ag.get_pi(root, 1)  # warm-up move (also pages torch in); not timed
+    t0 = time.perf_counter()
+    moves = 0
+    while time.perf_counter() - t0 < budget_s and moves < 40:
+        pi, vis, pol = ag.get_pi(root, 1 if len(root) <= 6 else 0)
+        a = ag.rng.choice_p(pi)
+        root = root + (int(a),)
+        moves += 1
+        if O.check_win(O.get_board(list(root)[1:], board), 3 if board == 3 else 5) != 0:
+            ag.reset()
+            root = (0,)
+    dt = time.perf_counter() - t0
+    return dict(value=moves / dt, unit="move-decisions/s", cores=cores, kind="port",
+                sample="%d move decisions of one 9x9 game, %d sims each, oracle C tree + PyTorch-CPU "
+                       "PVNet at batch 1, %d threads, %.1f s" % (moves, sims, cores, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=400)
+    ap.add_argument("--board", type=int, default=9)
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--planes", type=int, default=128)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from alpha_omok_amd.engine import Engine
+    from alpha_omok_amd.pvnet import PVNet
+
+    B, S, G = args.board, args.sims, args.games
+    torch.manual_seed(0)
+    model = PVNet(args.blocks, 5, args.planes, B)  # random init, BN gamma 1 / beta 0 (model.py:86-89)
+    model.eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    net = model.to_native(local)
+    eng = Engine(B, S, 5, games=G, noise=True, device=local)
+    base_seed = rank * G
+    eng.seed_all(np.arange(base_seed, base_seed + G, dtype=np.uint32))
+    next_seed = [world * G + rank]
+    ply = np.zeros(G, np.int64)
+    counters = dict(moves=0, games=0, levels=0, evaluated=0, terminal=0)
+
+    def step(count):
+        tau = (ply < 6).astype(np.int8)  # main.py:150-153 TAU_THRES
+        eng.search(net, tau=tau)
+        st = eng.search_stats()
+        act, win = eng.play()
+        ply[:] += 1
+        done = win != 0
+        if count:
+            counters["moves"] += G
+            counters["levels"] += st["levels"]
+            counters["evaluated"] += st["evaluated"]
+            counters["terminal"] += st["terminal"]
+            counters["games"] += int(done.sum())
+        if done.any():  # refill finished slots with fresh games (Agent.reset(), main.py:248)
+            eng.reset(done.astype(np.uint8))
+            for g in np.nonzero(done)[0]:
+                eng.seed(int(g), next_seed[0])
+                next_seed[0] += world
+            ply[done] = 0
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    net.conv_timing(True)  # reset + enable HIP-event timing of the trunk conv launches
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_launches = net.conv_timing(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_moves = world * G * args.steps
+    value = total_moves / dt_max
+
+    if rank == 0:
+        boards_padded = (G + 31) // 32 * 32
+        f_launch = trunk_conv_flops(B, args.planes, boards_padded)
+        avg_ms = conv_ms / max(conv_launches, 1)
+        achieved = f_launch / (avg_ms * 1e-3) / 1e12 if conv_launches else 0.0
+        sims_total = max(counters["evaluated"] + counters["terminal"], 1)
+        out = {
+            "metric": "self-play move-decisions/sec (9x9, 400 sims/move)",
+            "value": value,
+            "unit": "move-decisions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (self-play from the empty board, random-init weights, per-game seeds)",
+            "config": {
+                "workload": "BASELINE configs[2]: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "
+                            "leaf batch %d, random-init %d-block/%d-ch PVNet" % (B, B, G, S, G, args.blocks, args.planes),
+                "games_per_gpu": G, "sims": S, "board": B, "n_block": args.blocks, "planes": args.planes,
+                "parallelism": "games sharded over %d GPU(s), no data-path collective" % world,
+                "mean_select_depth": counters["levels"] / sims_total,
+                "terminal_leaf_fraction": counters["terminal"] / sims_total,
+                "games_finished": counters["games"],
+                "flops_per_move_algorithmic": S * eval_flops(B, 5, args.planes, args.blocks),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "k_conv3x3<9,9> (3x3 %d->%d trunk convolution, fp32 MFMA 32x32x2)" % (args.planes, args.planes),
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "flop_per_launch": f_launch,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": conv_launches,
+                "conv_time_share": (conv_ms * 1e-3) / dt if dt > 0 else None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(B, S, args.blocks, args.planes, sd, args.cpu_budget)
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "move-decisions/s", "cores": None,
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
