@@ -31,8 +31,9 @@ void launch_walk(const TreeParams& p, int g, const int32_t* extra, int m, int pr
                  int32_t* status_out, hipStream_t s);
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 // net.hip
-int net_forward_il(ao_net* n, const float* in_il, int groups, float* policy, float* value,
+int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
                    hipStream_t s);
+void net_plan(const ao_net* n, int boards, int* group, int* nchq);
 int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why);
 }  // namespace ao
 
@@ -145,7 +146,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     ao::TreeParams& p = e->tp;
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
-    p.nchq = (((c.inplanes + 3) / 4) + 1) & ~1;  // channel quads, consumed in pairs by the conv kernel
+    p.nchq = (((c.inplanes + 3) / 4) + 3) & ~3;  // worst case of the network's input layouts (net_plan)
+    p.il_group = ao::kGroup;
     p.c_puct = c.c_puct;
 
     const size_t slots = static_cast<size_t>(2) * G * p.cap;
@@ -496,10 +498,12 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     if (!net) return e->fail("ao_search: null network");
     std::string why;
     if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
+    // the network announces the interleaved input layout it wants for a batch of G boards
+    ao::net_plan(net, e->G, &e->tp.il_group, &e->tp.nchq);
     if (ao_begin_move(e, active)) return 1;
     while (e->sims_left > 0) {
         if (ao_collect_leaves(e, nullptr)) return 1;
-        if (ao::net_forward_il(net, e->tp.batch_il, e->Gp / ao::kGroup, e->d_policy, e->d_value, e->stream))
+        if (ao::net_forward_il(net, e->tp.batch_il, e->G, e->d_policy, e->d_value, e->stream))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
         if (ao_apply_evals(e, e->d_policy, e->d_value)) return 1;
     }

@@ -70,7 +70,8 @@ struct TreeParams {
     unsigned long long* stats;  // [4]: levels, ties, terminal leaves, evaluated leaves
     const double* sqrt_lut; int sqrt_lut_n;
     // evaluation batch
-    float* batch_il;      // interleaved [grp][cell][cq][32][4] (native network input) or null
+    float* batch_il;      // interleaved [grp][cell][cq][il_group][4] (native network input) or null
+    int il_group;         // boards per group of batch_il: 32 (layer kernels) or 16 (group-resident trunk)
     float* batch_nchw;    // [G][C][B][B] or null
     const float* policy;  // [G][A]
     const float* value;   // [G]

@@ -163,24 +163,158 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float4* __restrict__ in,
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Group-resident trunk: ONE workgroup carries a group of 16 boards through conv1 and all
+// residual blocks. G = 4096 games = 256 groups = one workgroup per CU of an MI355X, every CU does
+// identical work (no tail between layers, one launch instead of 1+2*n_block), and consecutive
+// layers need no device-wide synchronisation because a layer of a group only depends on the
+// previous layer of the same group: a workgroup barrier + an L1 invalidate is enough.
+//
+// MFMA shape: v_mfma_f32_16x16x4_f32, D[cout 16][board 16] += Wt[cout 16][k 4] * X[k 4][board 16].
+// Lane l loads 16 B = 4 input channels of channel quad cq0 + (l>>4) for board (B operand) or
+// output channel (A operand) l&15: a wave-wide fragment load is 1 KiB contiguous in
+// act[grp][cell][cq][16][4]. Wave w owns output-channel tile w (16 couts) and walks the board row
+// by row with BW accumulators (4 VGPR each); 8 waves = 128 output channels, 2 waves per SIMD.
+// ----------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TrunkLayer {
+    const float4* w;   // [9][cqi][COUT] float4
+    const float4* sc;  // [COUT/4]
+    const float4* sh;
+};
+
+constexpr int kMaxTrunkLayers = 44;
+
+struct TrunkArgs {
+    const float4* in0;  // [grp][A][cq0][16]
+    float4* bufA;       // [grp][A][CQ][16]
+    float4* bufB;
+    int nlayers, cq0, CQ, COUT;
+    TrunkLayer layers[kMaxTrunkLayers];
+};
+
+template <int BW, int XT>
+__global__ __launch_bounds__(512, 2) void k_trunk16(TrunkArgs a) {
+    constexpr int A = BW * BW;
+    constexpr int NXT = (BW + XT - 1) / XT;
+    constexpr int NX = XT + 2;
+    constexpr int GB = 16;
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ct = threadIdx.x >> 6;  // output-channel tile (16 couts) of this wave
+    const int kq = lane >> 4;         // which of the 4 channel quads of a k-step this lane loads
+    const int b = lane & 15;
+    const size_t gbase = static_cast<size_t>(grp) * A;
+    const int CQO = a.COUT >> 2;
+
+    for (int l = 0; l < a.nlayers; ++l) {
+        const float4* src = (l == 0) ? a.in0 : ((l & 1) ? a.bufA : a.bufB);
+        float4* dst = (l == 0) ? a.bufA : ((l & 1) ? a.bufB : a.bufA);
+        const bool res = (l > 0) && ((l & 1) == 0);  // second conv of a ResBlock: + x (held in bufA)
+        const int cqi = (l == 0) ? a.cq0 : a.CQ;
+        const float4* wt = a.layers[l].w;
+        const float4 sc = a.layers[l].sc[ct * 4 + kq];
+        const float4 sh = a.layers[l].sh[ct * 4 + kq];
+        const int ncqg = cqi >> 2;
+
+        for (int y = 0; y < BW; ++y) {
+            const int rlo = (y == 0) ? 1 : 0;
+            const int rhi = (y == BW - 1) ? 1 : 2;
+            const int nrows = rhi - rlo + 1;
+            const int nsteps = ncqg * nrows;
+            for (int xt = 0; xt < NXT; ++xt) {
+                const int x0 = (NXT == 1) ? 0 : xt * XT;
+                f32x4 acc[XT];
+#pragma unroll
+                for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+                auto load = [&](int s, StepRegs<NX>& R) {
+                    const int cqg = s / nrows;
+                    const int r = rlo + (s - cqg * nrows);
+                    const int yy = y - 1 + r;
+                    const int cq = cqg * 4 + kq;
+                    const float4* xp = src + ((gbase + static_cast<size_t>(yy) * BW) * cqi + cq) * GB + b;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        const int xi = x0 - 1 + j;
+                        if (xi >= 0 && xi < BW) R.x[j] = ld_frag(xp + static_cast<size_t>(xi) * cqi * GB);
+                    }
+                    const float4* wp = wt + (static_cast<size_t>(r * 3) * cqi + cq) * a.COUT + ct * 16 + b;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) R.w[dx] = ld_frag(wp + static_cast<size_t>(dx) * cqi * a.COUT);
+                };
+                auto compute = [&](const StepRegs<NX>& R) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {  // consecutive MFMAs hit different accumulators
+#pragma unroll
+                            for (int i = 0; i < XT; ++i) {
+                                const int xo = x0 + i;
+                                const int xi = xo + dx - 1;
+                                if (xo >= BW || xi < 0 || xi >= BW) continue;
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w[dx].v[t], R.x[i + dx].v[t], acc[i], 0, 0, 0);
+                            }
+                        }
+                    }
+                };
+
+                StepRegs<NX> Ra, Rb;
+                load(0, Ra);
+                for (int s = 0; s < nsteps; s += 2) {
+                    if (s + 1 < nsteps) load(s + 1, Rb);
+                    compute(Ra);
+                    if (s + 2 < nsteps) load(s + 2, Ra);
+                    if (s + 1 < nsteps) compute(Rb);
+                }
+                // epilogue: D row = cout 4*kq + reg, col = board b -> one float4 of 4 couts per lane
+#pragma unroll
+                for (int i = 0; i < XT; ++i) {
+                    const int xo = x0 + i;
+                    if (xo >= BW) continue;
+                    const size_t o = ((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b;
+                    float4 v;
+                    v.x = fmaf(acc[i][0], sc.x, sh.x);
+                    v.y = fmaf(acc[i][1], sc.y, sh.y);
+                    v.z = fmaf(acc[i][2], sc.z, sh.z);
+                    v.w = fmaf(acc[i][3], sc.w, sh.w);
+                    if (res) {
+                        const float4 rr = dst[o];
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    dst[o] = v;
+                }
+            }
+        }
+        // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
+        // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
 // hbuf[board][3][A]: channel 0,1 = policy head, 2 = value head.
 __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in, const float* __restrict__ w3,
                                                    const float* __restrict__ sc3, const float* __restrict__ sh3,
-                                                   float* __restrict__ hbuf, int A, int CQ) {
+                                                   float* __restrict__ hbuf, int A, int CQ, int GB) {
     extern __shared__ float s_w[];  // [3][planes]
     const int planes = CQ * 4;
     for (int i = threadIdx.x; i < 3 * planes; i += blockDim.x) s_w[i] = w3[i];
     __syncthreads();
-    const int nchunk = (A + 7) / 8;
+    const int ppb = 256 / GB;  // cells per block
+    const int nchunk = (A + ppb - 1) / ppb;
     const int grp = blockIdx.x / nchunk;
-    const int pos = (blockIdx.x - grp * nchunk) * 8 + (threadIdx.x >> 5);
-    const int b = threadIdx.x & 31;
+    const int pos = (blockIdx.x - grp * nchunk) * ppb + static_cast<int>(threadIdx.x) / GB;
+    const int b = static_cast<int>(threadIdx.x) % GB;
     if (pos >= A) return;
-    const float4* xp = in + ((static_cast<size_t>(grp) * A + pos) * CQ) * kGroup + b;
+    const float4* xp = in + ((static_cast<size_t>(grp) * A + pos) * CQ) * GB + b;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int cq = 0; cq < CQ; ++cq) {
-        const float4 x = xp[static_cast<size_t>(cq) * kGroup];
+        const float4 x = xp[static_cast<size_t>(cq) * GB];
         const float* w0 = s_w + 4 * cq;
         const float* w1 = s_w + planes + 4 * cq;
         const float* w2 = s_w + 2 * planes + 4 * cq;
@@ -188,7 +322,7 @@ __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in
         a1 = fmaf(x.x, w1[0], a1); a1 = fmaf(x.y, w1[1], a1); a1 = fmaf(x.z, w1[2], a1); a1 = fmaf(x.w, w1[3], a1);
         a2 = fmaf(x.x, w2[0], a2); a2 = fmaf(x.y, w2[1], a2); a2 = fmaf(x.z, w2[2], a2); a2 = fmaf(x.w, w2[3], a2);
     }
-    const size_t board = static_cast<size_t>(grp) * kGroup + b;
+    const size_t board = static_cast<size_t>(grp) * GB + b;
     float* h = hbuf + board * 3 * A + pos;
     h[0] = fmaxf(fmaf(a0, sc3[0], sh3[0]), 0.f);
     h[A] = fmaxf(fmaf(a1, sc3[1], sh3[1]), 0.f);
@@ -255,20 +389,20 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
 
 // [batch][C][A] float32 (Agent.model's input layout, agents.py:175) -> interleaved batch
 __global__ void k_nchw_to_il(const float* __restrict__ x, float4* __restrict__ il, int batch, int C, int A,
-                             int nchq, int boards_padded) {
+                             int nchq, int boards_padded, int GB) {
     const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t total = static_cast<size_t>(boards_padded) * A;
     if (i >= total) return;
     const int board = static_cast<int>(i / A), cell = static_cast<int>(i - static_cast<size_t>(board) * A);
-    const size_t grp = board >> 5;
-    const int b = board & 31;
+    const size_t grp = board / GB;
+    const int b = board % GB;
     for (int cq = 0; cq < nchq; ++cq) {
         float v[4];
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * cq + k;
             v[k] = (board < batch && c < C) ? x[(static_cast<size_t>(board) * C + c) * A + cell] : 0.f;
         }
-        il[((grp * A + cell) * nchq + cq) * kGroup + b] = make_float4(v[0], v[1], v[2], v[3]);
+        il[((grp * A + cell) * nchq + cq) * GB + b] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -279,19 +413,24 @@ __global__ void k_nchw_to_il(const float* __restrict__ x, float4* __restrict__ i
 // ==============================================================================================
 struct ao_net {
     int nb = 0, C = 0, planes = 0, B = 0, A = 0, device = 0;
-    int nchq = 0, CQ = 0;
+    int nchq32 = 0;  // input channel quads of the layer-kernel path (groups of 32 boards)
+    int nchq16 = 0;  // ... of the group-resident path (groups of 16 boards): multiple of 4
+    int CQ = 0;
+    int mode = 0;    // 0 auto, 1 layer kernels, 2 group-resident trunk
     bool finalized = false;
     std::string err;
     std::map<std::string, std::vector<float>> params;
     std::vector<void*> allocs;
     // device parameters
-    std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]
+    std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]; conv_w[0] packed for nchq32
+    float* conv0_w16 = nullptr;                    // conv1 weights packed for nchq16
     float *head_w3 = nullptr, *head_sc3 = nullptr, *head_sh3 = nullptr;
     float *wp_t = nullptr, *bp = nullptr, *w1_t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
-    // workspace
-    int ws_groups = 0;
+    // workspace (sized in boards, padded to 32)
+    int ws_boards = 0;
     float *act_x = nullptr, *act_t = nullptr, *hbuf = nullptr, *il_in = nullptr;
-    // timing of the trunk 3x3 convolutions
+    float *tmp_p = nullptr, *tmp_v = nullptr;
+    // timing of the dominant kernel (trunk conv launches)
     bool timing = false;
     static constexpr int kRing = 512;
     std::vector<hipEvent_t> ev0, ev1;
@@ -340,6 +479,19 @@ static void harvest(ao_net* n, int count) {
     }
 }
 
+static int timer_begin(ao_net* n, hipStream_t s) {
+    if (n->ring_count == ao_net::kRing) harvest(n, ao_net::kRing / 2);
+    const int idx = n->ring_head;
+    hipEventRecord(n->ev0[idx], s);
+    return idx;
+}
+
+static void timer_end(ao_net* n, int idx, hipStream_t s) {
+    hipEventRecord(n->ev1[idx], s);
+    n->ring_head = (n->ring_head + 1) % ao_net::kRing;
+    ++n->ring_count;
+}
+
 namespace ao {
 
 int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why) {
@@ -347,6 +499,18 @@ int net_check(const ao_net* n, int board, int inplanes, int device, std::string*
     if (n->B != board || n->C != inplanes) { *why = "network board/inplanes differ from the engine's"; return 1; }
     if (n->device != device) { *why = "network lives on another device"; return 1; }
     return 0;
+}
+
+// Execution plan for a batch of `boards` positions: which trunk runs and which interleaved input
+// layout (boards per group, channel quads) it expects. The group-resident trunk needs one
+// workgroup per 16 boards to fill the chip; below ~3/4 of the CUs the layer kernels (9 blocks
+// per 32 boards and layer) spread small batches over more CUs.
+void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
+    int mode = n->mode;
+    if (mode == 0) mode = ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
+    if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 1;
+    if (mode == 2) { *group = 16; *nchq = n->nchq16; }
+    else { *group = 32; *nchq = n->nchq32; }
 }
 
 template <int BW>
@@ -357,12 +521,7 @@ static void launch_conv(ao_net* n, int layer, const float* in, int cqi, const fl
     const int nblk = groups * BW * NXT;
     const dim3 grid(nblk), block(64 * (n->planes / 32));
     const bool timed = n->timing && layer > 0;
-    int idx = 0;
-    if (timed) {
-        if (n->ring_count == ao_net::kRing) harvest(n, ao_net::kRing / 2);
-        idx = n->ring_head;
-        hipEventRecord(n->ev0[idx], s);
-    }
+    const int idx = timed ? timer_begin(n, s) : 0;
     const float4* in4 = reinterpret_cast<const float4*>(in);
     const float4* w4 = reinterpret_cast<const float4*>(n->conv_w[layer]);
     const float4* sc4 = reinterpret_cast<const float4*>(n->conv_sc[layer]);
@@ -374,48 +533,93 @@ static void launch_conv(ao_net* n, int layer, const float* in, int cqi, const fl
     else
         hipLaunchKernelGGL((k_conv3x3<BW, XT, false>), grid, block, 0, s, in4, w4, sc4, sh4,
                            static_cast<const float4*>(nullptr), out4, cqi, n->planes, nblk);
-    if (timed) {
-        hipEventRecord(n->ev1[idx], s);
-        n->ring_head = (n->ring_head + 1) % ao_net::kRing;
-        ++n->ring_count;
-    }
+    if (timed) timer_end(n, idx, s);
 }
 
-static int ensure_workspace(ao_net* n, int groups) {
-    if (groups <= n->ws_groups) return 0;
+template <int BW>
+static void launch_trunk16(ao_net* n, const float* in_il, int groups, hipStream_t s) {
+    constexpr int XT = (BW <= 9) ? BW : 8;
+    TrunkArgs a;
+    a.in0 = reinterpret_cast<const float4*>(in_il);
+    a.bufA = reinterpret_cast<float4*>(n->act_x);
+    a.bufB = reinterpret_cast<float4*>(n->act_t);
+    a.nlayers = 1 + 2 * n->nb;
+    a.cq0 = n->nchq16;
+    a.CQ = n->CQ;
+    a.COUT = n->planes;
+    for (int l = 0; l < a.nlayers; ++l) {
+        a.layers[l].w = reinterpret_cast<const float4*>(l == 0 ? n->conv0_w16 : n->conv_w[l]);
+        a.layers[l].sc = reinterpret_cast<const float4*>(n->conv_sc[l]);
+        a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+    }
+    const int idx = n->timing ? timer_begin(n, s) : 0;
+    // 96 KiB of (unused) dynamic LDS pins one workgroup per CU: with 256 groups every CU of the
+    // chip gets exactly one group instead of some CUs receiving two
+    hipLaunchKernelGGL((k_trunk16<BW, XT>), dim3(groups), dim3(64 * (n->planes / 16)), 96 * 1024, s, a);
+    if (n->timing) timer_end(n, idx, s);
+}
+
+static int ensure_workspace(ao_net* n, int boards) {
+    boards = (boards + 31) / 32 * 32;
+    if (boards <= n->ws_boards) return 0;
     // grow-only; old buffers stay in n->allocs until destroy (forward sizes rarely change)
-    const size_t act = static_cast<size_t>(groups) * n->A * n->planes * kGroup;
+    const size_t act = static_cast<size_t>(boards) * n->A * n->planes;
     if (net_alloc(n, &n->act_x, act) || net_alloc(n, &n->act_t, act) ||
-        net_alloc(n, &n->hbuf, static_cast<size_t>(groups) * kGroup * 3 * n->A) ||
-        net_alloc(n, &n->il_in, static_cast<size_t>(groups) * n->A * n->nchq * 4 * kGroup))
+        net_alloc(n, &n->hbuf, static_cast<size_t>(boards) * 3 * n->A) ||
+        net_alloc(n, &n->il_in, static_cast<size_t>(boards) * n->A * std::max(n->nchq16, n->nchq32) * 4) ||
+        net_alloc(n, &n->tmp_p, static_cast<size_t>(boards) * n->A) || net_alloc(n, &n->tmp_v, boards))
         return 1;
-    n->ws_groups = groups;
+    n->ws_boards = boards;
     return 0;
 }
 
-int net_forward_il(ao_net* n, const float* in_il, int groups, float* policy, float* value, hipStream_t s) {
+// in_il: interleaved batch in the layout net_plan(n, boards) announced. policy/value must have
+// room for `boards` rounded up to the plan's group size.
+int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s) {
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
-    if (ensure_workspace(n, groups)) return 1;
-    auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
+    if (ensure_workspace(n, boards)) return 1;
+    int group = 32, nchq = 0;
+    net_plan(n, boards, &group, &nchq);
+    const int groups = (boards + group - 1) / group;
+    if (group == 16) {
+        static bool lds_attr_done[16] = {};
         switch (n->B) {
-#define AO_BW_CASE(W) case W: launch_conv<W>(n, layer, in, cqi, res, out, groups, s); break;
+#define AO_BW_CASE(W)                                                                                        \
+    case W: {                                                                                                \
+        constexpr int XT_ = (W <= 9) ? W : 8;                                                                \
+        if (!lds_attr_done[W])                                                                               \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16<W, XT_>),                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
+        lds_attr_done[W] = true;                                                                             \
+        launch_trunk16<W>(n, in_il, groups, s);                                                              \
+    } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
             AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
         }
-    };
-    conv(0, in_il, n->nchq, nullptr, n->act_x);                       // conv1 + bn1 + relu
-    for (int i = 0; i < n->nb; ++i) {                                  // ResBlock (model.py:22-31)
-        conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
-        conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
+    } else {
+        auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
+            switch (n->B) {
+#define AO_BW_CASE(W) case W: launch_conv<W>(n, layer, in, cqi, res, out, groups, s); break;
+                AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+                AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+            }
+        };
+        conv(0, in_il, n->nchq32, nullptr, n->act_x);                      // conv1 + bn1 + relu
+        for (int i = 0; i < n->nb; ++i) {                                   // ResBlock (model.py:22-31)
+            conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
+            conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
+        }
     }
-    const int nchunk = (n->A + 7) / 8;
+    const int ppb = 256 / group;
+    const int nchunk = (n->A + ppb - 1) / ppb;
     hipLaunchKernelGGL(k_head_conv, dim3(groups * nchunk), dim3(256), 3 * n->planes * sizeof(float), s,
                        reinterpret_cast<const float4*>(n->act_x), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf,
-                       n->A, n->CQ);
+                       n->A, n->CQ, group);
     const size_t lds = (static_cast<size_t>(4) * n->A + n->planes + 8) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fc, dim3(groups * kGroup), dim3(256), lds, s, n->hbuf, n->wp_t, n->bp, n->w1_t,
+    hipLaunchKernelGGL(k_head_fc, dim3(groups * group), dim3(256), lds, s, n->hbuf, n->wp_t, n->bp, n->w1_t,
                        n->b1, n->w2, n->b2, policy, value, n->A, n->planes);
     NET_HIP(n, hipGetLastError());
     return 0;
@@ -440,8 +644,9 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     if (device < 0 || device >= ndev) return bad("device ordinal out of range");
     ao_net* n = new ao_net();
     n->nb = n_block; n->C = inplanes; n->planes = planes; n->B = board; n->A = board * board;
-    n->device = device; n->nchq = (inplanes + 3) / 4;
-    if (n->nchq & 1) n->nchq += 1;  // the conv kernel consumes channel quads in pairs
+    n->device = device;
+    n->nchq32 = (((inplanes + 3) / 4) + 1) & ~1;  // consumed in pairs (32x32x2 MFMA, two quads per step)
+    n->nchq16 = (((inplanes + 3) / 4) + 3) & ~3;  // consumed in fours (16x16x4 MFMA)
     n->CQ = planes / 4;
     *out = n;
     return 0;
@@ -455,6 +660,12 @@ void ao_net_destroy(ao_net* n) {
     for (auto e : n->ev0) hipEventDestroy(e);
     for (auto e : n->ev1) hipEventDestroy(e);
     delete n;
+}
+
+int ao_net_set_mode(ao_net* n, int mode) {
+    if (mode < 0 || mode > 2) return n->fail("mode must be 0 (auto), 1 (layer kernels) or 2 (group-resident trunk)");
+    n->mode = mode;
+    return 0;
 }
 
 int ao_net_set_param(ao_net* n, const char* name, const float* data, int64_t numel) {
@@ -489,31 +700,41 @@ static int fold_bn(ao_net* n, const std::string& prefix, int c, std::vector<floa
     return 0;
 }
 
+// OIHW -> [tap][cq][cout][4], input channels zero-padded to 4*cqi
+static std::vector<float> pack_conv(const std::vector<float>& w, int cout, int cin, int cqi) {
+    std::vector<float> packed(static_cast<size_t>(9) * cqi * cout * 4, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t)
+                packed[((static_cast<size_t>(t) * cqi + (ci >> 2)) * cout + co) * 4 + (ci & 3)] =
+                    w[(static_cast<size_t>(co) * cin + ci) * 9 + t];
+    return packed;
+}
+
 int ao_net_finalize(ao_net* n) {
     NET_HIP(n, hipSetDevice(n->device));
+    NET_HIP(n, hipDeviceSynchronize());
     for (void* p : n->allocs) hipFree(p);
     n->allocs.clear();
     n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
-    n->ws_groups = 0;
+    n->ws_boards = 0;
     const int P = n->planes, A = n->A;
     auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
         const std::vector<float>* w;
         if (get_param(n, wname, static_cast<size_t>(P) * cin * 9, &w)) return 1;
-        // OIHW -> [tap][cq][cout][4]
-        std::vector<float> packed(static_cast<size_t>(9) * cqi * P * 4, 0.f);
-        for (int co = 0; co < P; ++co)
-            for (int ci = 0; ci < cin; ++ci)
-                for (int t = 0; t < 9; ++t)
-                    packed[((static_cast<size_t>(t) * cqi + (ci >> 2)) * P + co) * 4 + (ci & 3)] =
-                        (*w)[(static_cast<size_t>(co) * cin + ci) * 9 + t];
         std::vector<float> sc, sh;
         if (fold_bn(n, bnname, P, &sc, &sh)) return 1;
         float *dw, *dsc, *dsh;
-        if (upload(n, &dw, packed) || upload(n, &dsc, sc) || upload(n, &dsh, sh)) return 1;
+        if (upload(n, &dw, pack_conv(*w, P, cin, cqi)) || upload(n, &dsc, sc) || upload(n, &dsh, sh)) return 1;
         n->conv_w.push_back(dw); n->conv_sc.push_back(dsc); n->conv_sh.push_back(dsh);
         return 0;
     };
-    if (add_conv("conv1.weight", "bn1", n->C, n->nchq)) return 1;
+    if (add_conv("conv1.weight", "bn1", n->C, n->nchq32)) return 1;
+    {
+        const std::vector<float>* w;
+        if (get_param(n, "conv1.weight", static_cast<size_t>(P) * n->C * 9, &w)) return 1;
+        if (upload(n, &n->conv0_w16, pack_conv(*w, P, n->C, n->nchq16))) return 1;
+    }
     for (int i = 0; i < n->nb; ++i) {
         const std::string pre = "layers." + std::to_string(i);
         if (add_conv(pre + ".conv1.weight", pre + ".bn1", P, n->CQ)) return 1;
@@ -556,30 +777,22 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
     if (batch < 1) return n->fail("batch must be >= 1");
     NET_HIP(n, hipSetDevice(n->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int groups = (batch + ao::kGroup - 1) / ao::kGroup;
-    if (ao::ensure_workspace(n, groups)) return 1;
-    const int boards = groups * ao::kGroup;
-    // policy/value rows of the padding boards are written too: run the heads into scratch when
-    // the batch is not a multiple of 32
-    float *pol = dev_policy, *val = dev_value;
-    float *tmp_p = nullptr, *tmp_v = nullptr;
-    if (boards != batch) {
-        NET_HIP(n, hipMalloc(reinterpret_cast<void**>(&tmp_p), sizeof(float) * boards * n->A));
-        NET_HIP(n, hipMalloc(reinterpret_cast<void**>(&tmp_v), sizeof(float) * boards));
-        pol = tmp_p; val = tmp_v;
-    }
+    if (ao::ensure_workspace(n, batch)) return 1;
+    int group = 32, nchq = 0;
+    ao::net_plan(n, batch, &group, &nchq);
+    const int boards = (batch + group - 1) / group * group;
+    // the heads write rows for the padding boards too: run into scratch unless the batch is whole
+    float* pol = (boards == batch) ? dev_policy : n->tmp_p;
+    float* val = (boards == batch) ? dev_value : n->tmp_v;
     const size_t total = static_cast<size_t>(boards) * n->A;
     hipLaunchKernelGGL(ao::k_nchw_to_il, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
-                       dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, n->nchq, boards);
-    int rc = ao::net_forward_il(n, n->il_in, groups, pol, val, s);
-    if (!rc && boards != batch) {
-        hipMemcpyAsync(dev_policy, tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(dev_value, tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s);
-        hipStreamSynchronize(s);
+                       dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, nchq, boards, group);
+    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s)) return 1;
+    if (boards != batch) {
+        NET_HIP(n, hipMemcpyAsync(dev_policy, n->tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s));
+        NET_HIP(n, hipMemcpyAsync(dev_value, n->tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s));
     }
-    if (tmp_p) hipFree(tmp_p);
-    if (tmp_v) hipFree(tmp_v);
-    return rc;
+    return 0;
 }
 
 int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launches) {
@@ -598,6 +811,31 @@ int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launche
     n->ms_total = 0.0;
     n->launches = 0;
     n->timing = enable != 0;
+    return 0;
+}
+
+int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, double* flop_per_launch) {
+    int group = 32, nchq = 0;
+    ao::net_plan(n, boards, &group, &nchq);
+    const int padded = (boards + group - 1) / group * group;
+    const double conv = 2.0 * n->A * 9.0 * n->planes * n->planes * padded;   // one planes->planes 3x3 conv
+    const double conv1 = 2.0 * n->A * 9.0 * n->C * n->planes * padded;
+    std::string nm;
+    double f;
+    if (group == 16) {
+        nm = "k_trunk16<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
+             " 3x3 convs, one launch, fp32 MFMA 16x16x4)";
+        f = conv1 + 2.0 * n->nb * conv;
+    } else {
+        nm = "k_conv3x3<" + std::to_string(n->B) + "> (one 3x3 " + std::to_string(n->planes) + "->" +
+             std::to_string(n->planes) + " conv, fp32 MFMA 32x32x2)";
+        f = conv;
+    }
+    if (name && name_cap > 0) {
+        std::strncpy(name, nm.c_str(), static_cast<size_t>(name_cap) - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (flop_per_launch) *flop_per_launch = f;
     return 0;
 }
 

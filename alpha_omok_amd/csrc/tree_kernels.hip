@@ -247,12 +247,12 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
             for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = pl[q];
         }
         if (p.batch_il) {
-            const size_t grp = static_cast<size_t>(g >> 5);
-            const int b = g & 31;
+            const size_t grp = static_cast<size_t>(g / p.il_group);
+            const int b = g % p.il_group;
             for (int cq = 0; cq < p.nchq; ++cq) {
                 float4 v4 = make_float4(pl[4 * cq], pl[4 * cq + 1], pl[4 * cq + 2], pl[4 * cq + 3]);
                 float4* dst = reinterpret_cast<float4*>(p.batch_il) +
-                              (((grp * p.A + cell) * p.nchq + cq) * kGroup + b);
+                              (((grp * p.A + cell) * p.nchq + cq) * p.il_group + b);
                 *dst = v4;
             }
         }

@@ -62,6 +62,18 @@ class Net:
         self.forward_ptr(x.data_ptr(), batch, pol.data_ptr(), val.data_ptr(), stream)
         return pol, val
 
+    def set_mode(self, mode):
+        """0 auto, 1 layer kernels (groups of 32), 2 group-resident trunk (groups of 16)."""
+        self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
+
+    def dominant_kernel(self, boards):
+        """(name, algorithmic FLOPs per launch) of the kernel conv_timing() measures."""
+        buf = C.create_string_buffer(256)
+        f = C.c_double(0)
+        self._check(self._L.ao_net_dominant_kernel(self._h, int(boards), buf, 256, C.byref(f)),
+                    "ao_net_dominant_kernel")
+        return buf.value.decode(), f.value
+
     def conv_timing(self, enable=True):
         """Returns (total ms, launches) of the trunk 3x3 conv kernel since the last call."""
         ms, cnt = C.c_double(0), C.c_int64(0)

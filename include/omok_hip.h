@@ -135,9 +135,16 @@ int  ao_net_finalize(ao_net *n); /* fold BN running stats, repack weights for th
  * [batch][A], dev_value [batch]; `stream` is a hipStream_t (NULL = default stream). */
 int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *dev_policy,
                     float *dev_value, void *stream);
-/* average device time (ms) and launch count of the 3x3 trunk convolution kernel since the
- * last call (HIP events on the launch stream); used by bench.py's roofline. */
+/* Trunk execution: 0 = auto (by batch size), 1 = one kernel per 3x3 conv over groups of 32 boards
+ * (small batches), 2 = group-resident trunk: one workgroup carries 16 boards through every conv
+ * layer in a single launch (4096 boards = 256 groups = one per CU). Same numerics class (fp32). */
+int  ao_net_set_mode(ao_net *n, int mode);
+/* total device time (ms) and launch count of the dominant trunk kernel since the last call
+ * (HIP events on the launch stream); used by bench.py's roofline. */
 int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launches);
+/* name and algorithmic FLOPs per launch (2*MAC, zero padding counted) of the kernel the timing
+ * refers to, for a batch of `boards` positions. */
+int  ao_net_dominant_kernel(ao_net *n, int boards, char *name, int name_cap, double *flop_per_launch);
 
 #ifdef __cplusplus
 }

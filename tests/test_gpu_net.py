@@ -18,12 +18,15 @@ def _native(nb, C, planes, B, seed):
     return net
 
 
-def test_golden_gv7_forward():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_golden_gv7_forward(mode):
+    """mode 1: one kernel per conv (groups of 32 boards); mode 2: group-resident trunk (16)."""
     import torch
     g = load_golden("gv7_pvnet_forward")
     for i in range(int(g["count"])):
         nb, B, planes, wseed = g["cfg%d" % i].tolist()
         net = _native(nb, 5, planes, B, wseed)
+        net.set_mode(mode)
         x = torch.from_numpy(g["x%d" % i]).cuda()
         p, v = net(x)
         torch.cuda.synchronize()
@@ -34,9 +37,10 @@ def test_golden_gv7_forward():
         net.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("nb,B,planes,batch", [(4, 9, 128, 70), (10, 9, 128, 33), (2, 15, 128, 40),
                                                (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64)])
-def test_forward_vs_torch_fp32(nb, B, planes, batch):
+def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
     import torch
     from alpha_omok_amd.pvnet import PVNet
     sd = pvnet_weights.make_state_dict(nb, 5, planes, B, 100 + nb)
@@ -49,6 +53,7 @@ def test_forward_vs_torch_fp32(nb, B, planes, batch):
     with torch.no_grad():
         rp, rv = ref(torch.from_numpy(x))
     net = ref.to_native(0)
+    net.set_mode(mode)
     p, v = net(torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
     dp = np.abs(p.cpu().numpy() - rp.numpy()).max()
@@ -57,7 +62,8 @@ def test_forward_vs_torch_fp32(nb, B, planes, batch):
     net.close()
 
 
-def test_fused_search_matches_stepwise_and_oracle(oracle):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_search_matches_stepwise_and_oracle(oracle, mode):
     """ao_search (select -> native PVNet -> expand on one stream) == the stepwise protocol fed by
     the same network through ao_net_forward, and == the oracle replaying those (p, v)."""
     import torch
@@ -65,6 +71,7 @@ def test_fused_search_matches_stepwise_and_oracle(oracle):
     from gpu_helpers import HostEvalRunner
     B, S, G, plies = 9, 64, 33, 3
     net = _native(2, 5, 64, B, 42)
+    net.set_mode(mode)
     seeds = [500 + g for g in range(G)]
     e1 = Engine(B, S, 5, games=G, noise=True)
     e2 = Engine(B, S, 5, games=G, noise=True)
