@@ -194,100 +194,155 @@ struct TrunkArgs {
     TrunkLayer layers[kMaxTrunkLayers];
 };
 
-template <int BW, int XT>
-__global__ __launch_bounds__(512, 2) void k_trunk16(TrunkArgs a) {
-    constexpr int A = BW * BW;
+// One conv layer of one group. The K loop is a single stream of steps (unit = XT cells of a board
+// row; step = 16 input channels x one input row) that runs across unit boundaries: while step s
+// is in the matrix pipe the fragments of step s+1 -- possibly the first step of the next unit --
+// are in flight, and a unit's epilogue overlaps the next unit's first loads. Every load is
+// unconditional (out-of-range cells are clamped, their MFMAs skipped) so the compiler can keep
+// counted s_waitcnt vmcnt(N) instead of draining the queue.
+template <int BW, int XT, bool PIPE>
+__device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
+                                            const float4* __restrict__ wt, const float4 sc, const float4 sh,
+                                            const bool RES, int cqi, int COUT, size_t gbase, int ct, int kq,
+                                            int b) {
     constexpr int NXT = (BW + XT - 1) / XT;
     constexpr int NX = XT + 2;
     constexpr int GB = 16;
+    constexpr int NU = BW * NXT;
+    const int CQO = COUT >> 2;
+    const int ncqg = cqi >> 2;
+
+    auto nsteps_of = [&](int u) {
+        const int y = u / NXT;
+        return ncqg * ((y == 0 || y == BW - 1) ? 2 : 3);
+    };
+    auto load = [&](int u, int s, StepRegs<NX>& R) {
+        const int y = u / NXT;
+        const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
+        const int rlo = (y == 0) ? 1 : 0;
+        const int nrows = (y == 0 || y == BW - 1) ? 2 : 3;
+        const int cqg = s / nrows;
+        const int r = rlo + (s - cqg * nrows);
+        const int yy = y - 1 + r;
+        const int cq = cqg * 4 + kq;
+        const float4* xp = src + ((gbase + static_cast<size_t>(yy) * BW) * cqi + cq) * GB + b;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            if (NXT == 1 && (j == 0 || j == NX - 1)) continue;  // statically outside the board
+            int xi = x0 - 1 + j;
+            xi = xi < 0 ? 0 : (xi >= BW ? BW - 1 : xi);
+            R.x[j] = ld_frag(xp + static_cast<size_t>(xi) * cqi * GB);
+        }
+        const float4* wp = wt + (static_cast<size_t>(r * 3) * cqi + cq) * COUT + ct * 16 + b;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) R.w[dx] = ld_frag(wp + static_cast<size_t>(dx) * cqi * COUT);
+    };
+    f32x4 acc[XT];
+    auto compute = [&](const StepRegs<NX>& R, int x0) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {  // consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int i = 0; i < XT; ++i) {
+                    const int xo = x0 + i;
+                    const int xi = xo + dx - 1;
+                    if (xo >= BW || xi < 0 || xi >= BW) continue;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w[dx].v[t], R.x[i + dx].v[t], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // epilogue: D row = cout 4*kq + reg, col = board b -> one float4 of 4 couts per lane
+    auto epilogue = [&](int u) {
+        const int y = u / NXT;
+        const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
+        float4 rr[XT];
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) {
+                int xo = x0 + i;
+                xo = xo >= BW ? BW - 1 : xo;
+                rr[i] = dst[((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            const int xo = x0 + i;
+            float4 v;
+            v.x = fmaf(acc[i][0], sc.x, sh.x);
+            v.y = fmaf(acc[i][1], sc.y, sh.y);
+            v.z = fmaf(acc[i][2], sc.z, sh.z);
+            v.w = fmaf(acc[i][3], sc.w, sh.w);
+            if (RES) { v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w; }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            if (xo < BW) dst[((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b] = v;
+        }
+    };
+
+    StepRegs<NX> Ra, Rb;
+    if (PIPE) {  // requires an even number of steps per unit (ncqg even)
+        load(0, 0, Ra);
+        for (int u = 0; u < NU; ++u) {
+            const int y = u / NXT;
+            const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
+            const int nsteps = nsteps_of(u);
+#pragma unroll
+            for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < nsteps; s += 2) {
+                // sched_barrier pins "issue all loads of the next step, then the MFMAs of this one":
+                // left alone, the scheduler sinks the loads next to their first use
+                load(u, s + 1, Rb);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Ra, x0);
+                __builtin_amdgcn_sched_barrier(0);
+                // next step: same unit, first step of the next unit, or (end of the layer) a harmless
+                // re-load that keeps the number of outstanding loads uniform
+                const bool same = s + 2 < nsteps;
+                const bool last = !same && (u + 1 >= NU);
+                load(same || last ? u : u + 1, same ? s + 2 : (last ? s + 1 : 0), Ra);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(Rb, x0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            epilogue(u);
+        }
+    } else {
+        for (int u = 0; u < NU; ++u) {
+            const int y = u / NXT;
+            const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
+            const int nsteps = nsteps_of(u);
+#pragma unroll
+            for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < nsteps; ++s) {
+                load(u, s, Ra);
+                compute(Ra, x0);
+            }
+            epilogue(u);
+        }
+    }
+}
+
+template <int BW, int XT>
+__global__ __launch_bounds__(512, 2) void k_trunk16(TrunkArgs a) {
+    constexpr int A = BW * BW;
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int ct = threadIdx.x >> 6;  // output-channel tile (16 couts) of this wave
     const int kq = lane >> 4;         // which of the 4 channel quads of a k-step this lane loads
     const int b = lane & 15;
     const size_t gbase = static_cast<size_t>(grp) * A;
-    const int CQO = a.COUT >> 2;
 
     for (int l = 0; l < a.nlayers; ++l) {
         const float4* src = (l == 0) ? a.in0 : ((l & 1) ? a.bufA : a.bufB);
         float4* dst = (l == 0) ? a.bufA : ((l & 1) ? a.bufB : a.bufA);
-        const bool res = (l > 0) && ((l & 1) == 0);  // second conv of a ResBlock: + x (held in bufA)
-        const int cqi = (l == 0) ? a.cq0 : a.CQ;
         const float4* wt = a.layers[l].w;
         const float4 sc = a.layers[l].sc[ct * 4 + kq];
         const float4 sh = a.layers[l].sh[ct * 4 + kq];
-        const int ncqg = cqi >> 2;
-
-        for (int y = 0; y < BW; ++y) {
-            const int rlo = (y == 0) ? 1 : 0;
-            const int rhi = (y == BW - 1) ? 1 : 2;
-            const int nrows = rhi - rlo + 1;
-            const int nsteps = ncqg * nrows;
-            for (int xt = 0; xt < NXT; ++xt) {
-                const int x0 = (NXT == 1) ? 0 : xt * XT;
-                f32x4 acc[XT];
-#pragma unroll
-                for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-                auto load = [&](int s, StepRegs<NX>& R) {
-                    const int cqg = s / nrows;
-                    const int r = rlo + (s - cqg * nrows);
-                    const int yy = y - 1 + r;
-                    const int cq = cqg * 4 + kq;
-                    const float4* xp = src + ((gbase + static_cast<size_t>(yy) * BW) * cqi + cq) * GB + b;
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) {
-                        const int xi = x0 - 1 + j;
-                        if (xi >= 0 && xi < BW) R.x[j] = ld_frag(xp + static_cast<size_t>(xi) * cqi * GB);
-                    }
-                    const float4* wp = wt + (static_cast<size_t>(r * 3) * cqi + cq) * a.COUT + ct * 16 + b;
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) R.w[dx] = ld_frag(wp + static_cast<size_t>(dx) * cqi * a.COUT);
-                };
-                auto compute = [&](const StepRegs<NX>& R) {
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {  // consecutive MFMAs hit different accumulators
-#pragma unroll
-                            for (int i = 0; i < XT; ++i) {
-                                const int xo = x0 + i;
-                                const int xi = xo + dx - 1;
-                                if (xo >= BW || xi < 0 || xi >= BW) continue;
-                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w[dx].v[t], R.x[i + dx].v[t], acc[i], 0, 0, 0);
-                            }
-                        }
-                    }
-                };
-
-                StepRegs<NX> Ra, Rb;
-                load(0, Ra);
-                for (int s = 0; s < nsteps; s += 2) {
-                    if (s + 1 < nsteps) load(s + 1, Rb);
-                    compute(Ra);
-                    if (s + 2 < nsteps) load(s + 2, Ra);
-                    if (s + 1 < nsteps) compute(Rb);
-                }
-                // epilogue: D row = cout 4*kq + reg, col = board b -> one float4 of 4 couts per lane
-#pragma unroll
-                for (int i = 0; i < XT; ++i) {
-                    const int xo = x0 + i;
-                    if (xo >= BW) continue;
-                    const size_t o = ((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b;
-                    float4 v;
-                    v.x = fmaf(acc[i][0], sc.x, sh.x);
-                    v.y = fmaf(acc[i][1], sc.y, sh.y);
-                    v.z = fmaf(acc[i][2], sc.z, sh.z);
-                    v.w = fmaf(acc[i][3], sc.w, sh.w);
-                    if (res) {
-                        const float4 rr = dst[o];
-                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                    }
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    dst[o] = v;
-                }
-            }
-        }
+        if (l == 0)  // conv1: a single 16-channel k-step per input row
+            trunk_layer<BW, XT, false>(src, dst, wt, sc, sh, false, a.cq0, a.COUT, gbase, ct, kq, b);
+        else  // even l: second conv of a ResBlock, + x (held in bufA = dst)
+            trunk_layer<BW, XT, true>(src, dst, wt, sc, sh, (l & 1) == 0, a.CQ, a.COUT, gbase, ct, kq, b);
         // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
         // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--planes", type=int, default=128)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trunk-mode", type=int, default=0, help="0 auto, 1 layer kernels, 2 group-resident trunk")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +119,7 @@ def main():
     model.eval()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     net = model.to_native(local)
+    net.set_mode(args.trunk_mode)
     eng = Engine(B, S, 5, games=G, noise=True, device=local)
     base_seed = rank * G
     eng.seed_all(np.arange(base_seed, base_seed + G, dtype=np.uint32))
@@ -172,8 +174,7 @@ def main():
     value = total_moves / dt_max
 
     if rank == 0:
-        boards_padded = (G + 31) // 32 * 32
-        f_launch = trunk_conv_flops(B, args.planes, boards_padded)
+        kname, f_launch = net.dominant_kernel(G)
         avg_ms = conv_ms / max(conv_launches, 1)
         achieved = f_launch / (avg_ms * 1e-3) / 1e12 if conv_launches else 0.0
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
@@ -202,7 +203,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_conv3x3<9,9> (3x3 %d->%d trunk convolution, fp32 MFMA 32x32x2)" % (args.planes, args.planes),
+                "kernel": kname,
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
