@@ -25,8 +25,10 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -45,6 +47,22 @@ __device__ __forceinline__ Frag ld_frag(const float4* p) {
     const float4 t = *p;
     Frag f;
     f.v[0] = t.x; f.v[1] = t.y; f.v[2] = t.z; f.v[3] = t.w;
+    return f;
+}
+
+// Buffer-descriptor loads/stores: address = descriptor base (SGPRs) + per-lane 32-bit voffset +
+// wave-uniform soffset (an SGPR). A step's dozens of fragment loads then share ONE address VGPR.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ Frag buf_ld_frag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    Frag f;
+    f.v[0] = __uint_as_float(t.x); f.v[1] = __uint_as_float(t.y);
+    f.v[2] = __uint_as_float(t.z); f.v[3] = __uint_as_float(t.w);
     return f;
 }
 
@@ -194,141 +212,178 @@ struct TrunkArgs {
     TrunkLayer layers[kMaxTrunkLayers];
 };
 
-// One conv layer of one group. The K loop is a single stream of steps (unit = XT cells of a board
-// row; step = 16 input channels x one input row) that runs across unit boundaries: while step s
-// is in the matrix pipe the fragments of step s+1 -- possibly the first step of the next unit --
-// are in flight, and a unit's epilogue overlaps the next unit's first loads. Every load is
-// unconditional (out-of-range cells are clamped, their MFMAs skipped) so the compiler can keep
-// counted s_waitcnt vmcnt(N) instead of draining the queue.
-template <int BW, int XT, bool PIPE>
+// One conv layer of one group, "sliding window" form. A wave owns TPW output-channel tiles and
+// keeps the accumulators of THREE output rows (3 x XT cells x TPW tiles, AGPRs). A step = one
+// input row yi x 16 input channels: its XT(+2) activation fragments and the 9 x TPW weight
+// fragments feed every (dy, dx) tap at once -- up to 75 x 4 x TPW MFMAs -- so each activation is
+// loaded exactly once per layer and wave (not once per output row) and a step of loads is covered
+// by ~10-20k cycles of matrix work. Activations are double-buffered one step ahead; the weight
+// fragments of tap row dy are re-loaded for the next step right after their last MFMA.
+// When input row yi is done, output row yi-1 is complete: its epilogue (BN scale/shift, residual,
+// ReLU, store) runs and the window slides (accumulator registers move down one row).
+template <int BW, int XT, int TPW>
 __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
-                                            const float4* __restrict__ wt, const float4 sc, const float4 sh,
-                                            const bool RES, int cqi, int COUT, size_t gbase, int ct, int kq,
-                                            int b) {
+                                            const float4* __restrict__ wt, const float4* __restrict__ scp,
+                                            const float4* __restrict__ shp, const bool RES, int cqi, int COUT,
+                                            size_t gbase, int ct0, int kq, int b) {
     constexpr int NXT = (BW + XT - 1) / XT;
     constexpr int NX = XT + 2;
     constexpr int GB = 16;
-    constexpr int NU = BW * NXT;
     const int CQO = COUT >> 2;
-    const int ncqg = cqi >> 2;
+    const int ncqg = cqi >> 2;  // even (asserted on the host)
 
-    auto nsteps_of = [&](int u) {
-        const int y = u / NXT;
-        return ncqg * ((y == 0 || y == BW - 1) ? 2 : 3);
-    };
-    auto load = [&](int u, int s, StepRegs<NX>& R) {
-        const int y = u / NXT;
-        const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
-        const int rlo = (y == 0) ? 1 : 0;
-        const int nrows = (y == 0 || y == BW - 1) ? 2 : 3;
-        const int cqg = s / nrows;
-        const int r = rlo + (s - cqg * nrows);
-        const int yy = y - 1 + r;
-        const int cq = cqg * 4 + kq;
-        const float4* xp = src + ((gbase + static_cast<size_t>(yy) * BW) * cqi + cq) * GB + b;
+    float4 sc[TPW], sh[TPW];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            if (NXT == 1 && (j == 0 || j == NX - 1)) continue;  // statically outside the board
-            int xi = x0 - 1 + j;
-            xi = xi < 0 ? 0 : (xi >= BW ? BW - 1 : xi);
-            R.x[j] = ld_frag(xp + static_cast<size_t>(xi) * cqi * GB);
-        }
-        const float4* wp = wt + (static_cast<size_t>(r * 3) * cqi + cq) * COUT + ct * 16 + b;
+    for (int tl = 0; tl < TPW; ++tl) {
+        sc[tl] = scp[(ct0 + tl) * 4 + kq];
+        sh[tl] = shp[(ct0 + tl) * 4 + kq];
+    }
+
+    for (int xt = 0; xt < NXT; ++xt) {
+        const int x0 = (NXT == 1) ? 0 : xt * XT;
+        f32x4 acc0[XT][TPW], acc1[XT][TPW], acc2[XT][TPW];  // output rows yi-1, yi, yi+1
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) R.w[dx] = ld_frag(wp + static_cast<size_t>(dx) * cqi * COUT);
-    };
-    f32x4 acc[XT];
-    auto compute = [&](const StepRegs<NX>& R, int x0) {
+        for (int i = 0; i < XT; ++i)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+            for (int tl = 0; tl < TPW; ++tl) {
+                acc0[i][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc1[i][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc2[i][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        Frag xa[NX], xb[NX], w[3][3][TPW];
+
+        // Addresses are "buffer descriptor + one per-lane 32-bit offset + uniform SGPR offset" so
+        // the dozens of fragment loads of a step cost scalar, not vector, address arithmetic.
+        // Every load is unconditional (cells outside the board are clamped, their MFMAs skipped).
+        const int lane_x = (kq * GB + b) * 16;    // bytes inside one (cell, 4-quad) slab
+        const int lane_w = (kq * COUT + b) * 16;  // bytes inside one (tap, 4-quad) weight slab
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(src + gbase * cqi * GB, BW * BW * cqi * GB * 16u);
+        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wt, 9u * cqi * COUT * 16u);
+        const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(dst + gbase * CQO * GB, BW * BW * CQO * GB * 16u);
+        auto load_x = [&](int yi, int cqg, Frag (&X)[NX]) {
+            const int row = (yi * BW * cqi + cqg * 4) * GB * 16;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {  // consecutive MFMAs hit different accumulators
+            for (int j = 0; j < NX; ++j) {
+                if (NXT == 1 && (j == 0 || j == NX - 1)) continue;  // statically outside the board
+                int xi = x0 - 1 + j;
+                xi = xi < 0 ? 0 : (xi >= BW ? BW - 1 : xi);
+                X[j] = buf_ld_frag(rs_x, lane_x, row + xi * cqi * GB * 16);
+            }
+        };
+        auto load_w = [&](int cqg, int dy) {
+            const int row = ((dy * 3 * cqi + cqg * 4) * COUT + ct0 * 16) * 16;
 #pragma unroll
-                for (int i = 0; i < XT; ++i) {
-                    const int xo = x0 + i;
-                    const int xi = xo + dx - 1;
-                    if (xo >= BW || xi < 0 || xi >= BW) continue;
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.w[dx].v[t], R.x[i + dx].v[t], acc[i], 0, 0, 0);
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl)
+                    w[dy][dx][tl] = buf_ld_frag(rs_w, lane_w, row + (dx * cqi * COUT + tl * 16) * 16);
+        };
+        auto taps = [&](const Frag (&X)[NX], int dy, f32x4 (&acc)[XT][TPW]) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {  // consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl) {
+#pragma unroll
+                        for (int i = 0; i < XT; ++i) {
+                            const int xo = x0 + i;
+                            const int xi = xo + dx - 1;
+                            if (xo >= BW || xi < 0 || xi >= BW) continue;
+                            acc[i][tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[dy][dx][tl].v[t], X[i + dx].v[t],
+                                                                              acc[i][tl], 0, 0, 0);
+                        }
+                    }
                 }
             }
-        }
-    };
-    // epilogue: D row = cout 4*kq + reg, col = board b -> one float4 of 4 couts per lane
-    auto epilogue = [&](int u) {
-        const int y = u / NXT;
-        const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
-        float4 rr[XT];
-        if (RES) {
+        };
+        // one step: input row yi, channel group of X; (nyi, ncq) is the step after it
+        auto step = [&](const Frag (&X)[NX], Frag (&Xn)[NX], int yi, int nyi, int ncq) {
+            // sched_barrier keeps each weight re-load BELOW the last MFMA that reads the registers it
+            // overwrites; hoisted above, it would need a second copy of the weight fragments
+            load_x(nyi, ncq, Xn);
+            if (yi + 1 < BW) taps(X, 0, acc2);  // dy = 0 -> output row yi + 1
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(ncq, 0);
+            taps(X, 1, acc1);                   // dy = 1 -> output row yi
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(ncq, 1);
+            if (yi >= 1) taps(X, 2, acc0);      // dy = 2 -> output row yi - 1
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(ncq, 2);
+        };
+        // D row = cout 4*kq + reg, col = board b -> one float4 of 4 couts per lane
+        auto epilogue = [&](int yo) {
+            Frag rr[XT][TPW];
+            const int orow = (yo * BW * CQO + ct0 * 4) * GB * 16;
+            if (RES) {
+#pragma unroll
+                for (int i = 0; i < XT; ++i) {
+                    int xo = x0 + i;
+                    xo = xo >= BW ? BW - 1 : xo;
+#pragma unroll
+                    for (int tl = 0; tl < TPW; ++tl)
+                        rr[i][tl] = buf_ld_frag(rs_o, lane_x, orow + (xo * CQO + tl * 4) * GB * 16);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < XT; ++i) {
-                int xo = x0 + i;
-                xo = xo >= BW ? BW - 1 : xo;
-                rr[i] = dst[((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b];
-            }
-        }
+                const int xo = x0 + i;
 #pragma unroll
-        for (int i = 0; i < XT; ++i) {
-            const int xo = x0 + i;
-            float4 v;
-            v.x = fmaf(acc[i][0], sc.x, sh.x);
-            v.y = fmaf(acc[i][1], sc.y, sh.y);
-            v.z = fmaf(acc[i][2], sc.z, sh.z);
-            v.w = fmaf(acc[i][3], sc.w, sh.w);
-            if (RES) { v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w; }
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            if (xo < BW) dst[((gbase + static_cast<size_t>(y) * BW + xo) * CQO + ct * 4 + kq) * GB + b] = v;
-        }
-    };
+                for (int tl = 0; tl < TPW; ++tl) {
+                    const f32x4 c = acc0[i][tl];
+                    float vx = fmaf(c[0], sc[tl].x, sh[tl].x);
+                    float vy = fmaf(c[1], sc[tl].y, sh[tl].y);
+                    float vz = fmaf(c[2], sc[tl].z, sh[tl].z);
+                    float vw = fmaf(c[3], sc[tl].w, sh[tl].w);
+                    if (RES) { vx += rr[i][tl].v[0]; vy += rr[i][tl].v[1]; vz += rr[i][tl].v[2]; vw += rr[i][tl].v[3]; }
+                    u32x4 o;
+                    o.x = __float_as_uint(fmaxf(vx, 0.f)); o.y = __float_as_uint(fmaxf(vy, 0.f));
+                    o.z = __float_as_uint(fmaxf(vz, 0.f)); o.w = __float_as_uint(fmaxf(vw, 0.f));
+                    if (xo < BW)
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, lane_x, orow + (xo * CQO + tl * 4) * GB * 16, 0);
+                }
+            }
+        };
+        auto slide = [&]() {
+#pragma unroll
+            for (int i = 0; i < XT; ++i)
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl) {
+                    acc0[i][tl] = acc1[i][tl];
+                    acc1[i][tl] = acc2[i][tl];
+                    acc2[i][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        };
 
-    StepRegs<NX> Ra, Rb;
-    if (PIPE) {  // requires an even number of steps per unit (ncqg even)
-        load(0, 0, Ra);
-        for (int u = 0; u < NU; ++u) {
-            const int y = u / NXT;
-            const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
-            const int nsteps = nsteps_of(u);
-#pragma unroll
-            for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < nsteps; s += 2) {
-                // sched_barrier pins "issue all loads of the next step, then the MFMAs of this one":
-                // left alone, the scheduler sinks the loads next to their first use
-                load(u, s + 1, Rb);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(Ra, x0);
-                __builtin_amdgcn_sched_barrier(0);
-                // next step: same unit, first step of the next unit, or (end of the layer) a harmless
-                // re-load that keeps the number of outstanding loads uniform
-                const bool same = s + 2 < nsteps;
-                const bool last = !same && (u + 1 >= NU);
-                load(same || last ? u : u + 1, same ? s + 2 : (last ? s + 1 : 0), Ra);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(Rb, x0);
-                __builtin_amdgcn_sched_barrier(0);
+        load_x(0, 0, xa);
+        load_w(0, 0);
+        load_w(0, 1);
+        load_w(0, 2);
+        for (int yi = 0; yi < BW; ++yi) {
+            for (int cqg = 0; cqg < ncqg; cqg += 2) {
+                step(xa, xb, yi, yi, cqg + 1);
+                const bool same = cqg + 2 < ncqg;
+                const bool last = !same && (yi + 1 >= BW);  // end of the layer: harmless re-load
+                step(xb, xa, yi, same || last ? yi : yi + 1, same ? cqg + 2 : (last ? cqg + 1 : 0));
             }
-            epilogue(u);
+            if (yi >= 1) epilogue(yi - 1);
+            slide();
         }
-    } else {
-        for (int u = 0; u < NU; ++u) {
-            const int y = u / NXT;
-            const int x0 = (NXT == 1) ? 0 : (u - y * NXT) * XT;
-            const int nsteps = nsteps_of(u);
-#pragma unroll
-            for (int i = 0; i < XT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < nsteps; ++s) {
-                load(u, s, Ra);
-                compute(Ra, x0);
-            }
-            epilogue(u);
-        }
+        epilogue(BW - 1);  // after the last slide the bottom row sits in acc0
     }
 }
 
-template <int BW, int XT>
-__global__ __launch_bounds__(512, 2) void k_trunk16(TrunkArgs a) {
+// TPW = output-channel tiles per wave (1 is what runs: one wave per tile, two waves per SIMD).
+template <int BW, int XT, int TPW>
+__global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
     constexpr int A = BW * BW;
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int ct = threadIdx.x >> 6;  // output-channel tile (16 couts) of this wave
+    // readfirstlane makes the wave index provably uniform: it feeds buffer-load SGPR offsets, and a
+    // "divergent" offset would wrap every such load in a waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int ct0 = wave * TPW;       // first output-channel tile (16 couts) of this wave
     const int kq = lane >> 4;         // which of the 4 channel quads of a k-step this lane loads
     const int b = lane & 15;
     const size_t gbase = static_cast<size_t>(grp) * A;
@@ -336,13 +391,9 @@ __global__ __launch_bounds__(512, 2) void k_trunk16(TrunkArgs a) {
     for (int l = 0; l < a.nlayers; ++l) {
         const float4* src = (l == 0) ? a.in0 : ((l & 1) ? a.bufA : a.bufB);
         float4* dst = (l == 0) ? a.bufA : ((l & 1) ? a.bufB : a.bufA);
-        const float4* wt = a.layers[l].w;
-        const float4 sc = a.layers[l].sc[ct * 4 + kq];
-        const float4 sh = a.layers[l].sh[ct * 4 + kq];
-        if (l == 0)  // conv1: a single 16-channel k-step per input row
-            trunk_layer<BW, XT, false>(src, dst, wt, sc, sh, false, a.cq0, a.COUT, gbase, ct, kq, b);
-        else  // even l: second conv of a ResBlock, + x (held in bufA = dst)
-            trunk_layer<BW, XT, true>(src, dst, wt, sc, sh, (l & 1) == 0, a.CQ, a.COUT, gbase, ct, kq, b);
+        // even l > 0: second conv of a ResBlock, + x (held in bufA = dst)
+        trunk_layer<BW, XT, TPW>(src, dst, a.layers[l].w, a.layers[l].sc, a.layers[l].sh, l > 0 && (l & 1) == 0,
+                                 l == 0 ? a.cq0 : a.CQ, a.COUT, gbase, ct0, kq, b);
         // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
         // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -469,7 +520,7 @@ __global__ void k_nchw_to_il(const float* __restrict__ x, float4* __restrict__ i
 struct ao_net {
     int nb = 0, C = 0, planes = 0, B = 0, A = 0, device = 0;
     int nchq32 = 0;  // input channel quads of the layer-kernel path (groups of 32 boards)
-    int nchq16 = 0;  // ... of the group-resident path (groups of 16 boards): multiple of 4
+    int nchq16 = 0;  // ... of the group-resident path (groups of 16 boards): multiple of 8
     int CQ = 0;
     int mode = 0;    // 0 auto, 1 layer kernels, 2 group-resident trunk
     bool finalized = false;
@@ -593,7 +644,7 @@ static void launch_conv(ao_net* n, int layer, const float* in, int cqi, const fl
 
 template <int BW>
 static void launch_trunk16(ao_net* n, const float* in_il, int groups, hipStream_t s) {
-    constexpr int XT = (BW <= 9) ? BW : 8;
+    constexpr int XT = (BW <= 9) ? BW : 5;  // cells per window row: 3 rows x XT x 2 tiles of accumulators
     TrunkArgs a;
     a.in0 = reinterpret_cast<const float4*>(in_il);
     a.bufA = reinterpret_cast<float4*>(n->act_x);
@@ -610,7 +661,9 @@ static void launch_trunk16(ao_net* n, const float* in_il, int groups, hipStream_
     const int idx = n->timing ? timer_begin(n, s) : 0;
     // 96 KiB of (unused) dynamic LDS pins one workgroup per CU: with 256 groups every CU of the
     // chip gets exactly one group instead of some CUs receiving two
-    hipLaunchKernelGGL((k_trunk16<BW, XT>), dim3(groups), dim3(64 * (n->planes / 16)), 96 * 1024, s, a);
+    // one wave per output-channel tile: 8 waves (2 per SIMD) at 128 channels. (A 2-tiles-per-wave
+    // variant with the window in AGPRs was slower and is not instantiated.)
+    hipLaunchKernelGGL((k_trunk16<BW, XT, 1>), dim3(groups), dim3(64 * (n->planes / 16)), 96 * 1024, s, a);
     if (n->timing) timer_end(n, idx, s);
 }
 
@@ -642,10 +695,11 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
-        constexpr int XT_ = (W <= 9) ? W : 8;                                                                \
-        if (!lds_attr_done[W])                                                                               \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16<W, XT_>),                \
+        constexpr int XT_ = (W <= 9) ? W : 5;                                                                \
+        if (!lds_attr_done[W]) {                                                                             \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16<W, XT_, 1>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
+        }                                                                                                    \
         lds_attr_done[W] = true;                                                                             \
         launch_trunk16<W>(n, in_il, groups, s);                                                              \
     } break;
@@ -701,7 +755,7 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     n->nb = n_block; n->C = inplanes; n->planes = planes; n->B = board; n->A = board * board;
     n->device = device;
     n->nchq32 = (((inplanes + 3) / 4) + 1) & ~1;  // consumed in pairs (32x32x2 MFMA, two quads per step)
-    n->nchq16 = (((inplanes + 3) / 4) + 3) & ~3;  // consumed in fours (16x16x4 MFMA)
+    n->nchq16 = (((inplanes + 3) / 4) + 7) & ~7;  // 16 channels per k-step, steps taken in pairs
     n->CQ = planes / 4;
     *out = n;
     return 0;

@@ -228,9 +228,9 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
         if (cell >= p.A) continue;
-        float pl[16];
+        float pl[32];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pl[i] = 0.f;
+        for (int i = 0; i < 32; ++i) pl[i] = 0.f;
         for (int j = 0; j <= C - 2; ++j) {
             // X_{k-j}: mover of move k-j is the opponent of the side to move when j is even
             float v = 0.f;
