@@ -1,0 +1,73 @@
+"""Runs one move decision of an Engine with whatever `Agent.model` is (agents.py:171-178).
+
+  * PVNet-shaped torch module (state_dict wire format of model.py) -> exported to the native MFMA
+    forward (engine.Net); the whole move is one fused C call (ao_search), no host round trips;
+  * anything else callable as model(x[G,C,B,B]) -> (policy[G,A], value[G]) -> stepwise protocol,
+    one call per simulation on the whole leaf batch.
+"""
+import numpy as np
+
+from . import pvnet
+
+
+class Evaluator:
+    def __init__(self, device=0):
+        self.device = device
+        self._key = None
+        self._net = None
+        self._bufs = None
+
+    def native_net(self, model, board_size, inplanes):
+        cfg = pvnet.looks_like_pvnet(model)
+        if cfg is None or cfg[2] % 32 or cfg[2] > 128 or cfg[3] != board_size or cfg[1] != inplanes:
+            return None
+        version = sum(int(getattr(p, "_version", 0)) for p in model.state_dict().values())
+        key = (id(model), version)
+        if self._key != key:
+            from .engine import Net
+            if self._net is None or self._key is None or self._key[0] != key[0]:
+                self._net = Net(cfg[0], cfg[1], cfg[2], cfg[3], self.device)
+            self._net.load_state_dict(model.state_dict())
+            self._key = key
+        return self._net
+
+    @staticmethod
+    def _model_device(model):
+        import torch
+        try:
+            return next(model.parameters()).device
+        except Exception:
+            return torch.device("cpu")
+
+    def search(self, eng, model, tau, active=None, on_sim=None):
+        """Returns (pi, visit, policy) float64 [G, A]."""
+        tau = np.ascontiguousarray(np.broadcast_to(tau, (eng.G,)), np.int8)
+        net = model if hasattr(model, "forward_ptr") else self.native_net(model, eng.board_size, eng.inplanes)
+        if net is not None:
+            return eng.search(net, tau=tau, active=active)
+        import torch
+        dev = torch.device("cuda", self.device)
+        G, C, B, A = eng.G, eng.inplanes, eng.board_size, eng.A
+        if self._bufs is None or self._bufs[0].shape[0] != G:
+            self._bufs = (torch.zeros((G, C, B, B), dtype=torch.float32, device=dev),
+                          torch.zeros((G, A), dtype=torch.float32, device=dev),
+                          torch.zeros((G,), dtype=torch.float32, device=dev))
+        planes, pol, val = self._bufs
+        mdev = self._model_device(model)
+        if hasattr(model, "eval"):
+            model.eval()
+        eng.begin_move(active)
+        i = 0
+        while eng.sims_left() > 0:
+            i += 1
+            if on_sim is not None:
+                on_sim(i)
+            eng.collect_leaves(planes.data_ptr())
+            eng.sync()
+            with torch.no_grad():
+                p, v = model(planes.to(mdev))
+            pol.copy_(p.reshape(G, A).to(dev, torch.float32))
+            val.copy_(v.reshape(G).to(dev, torch.float32))
+            torch.cuda.synchronize(dev)
+            eng.apply_evals(pol.data_ptr(), val.data_ptr())
+        return eng.end_move(tau)

@@ -1,0 +1,234 @@
+"""Drop-in for the reference's `main.self_play` / `main.train` (main.py:122-336).
+
+Same module-level names as the reference (constants, `Agent`, `optimizer`, `rep_memory`,
+`cur_memory`, `result`, `step`), so a driver written against `main` keeps working:
+
+    import alpha_omok_amd.main as main
+    main.configure(board_size=9, n_mcts=400, n_blocks=4)   # replaces editing the constants
+    main.self_play(4096)       # 4096 games CONCURRENTLY on the local MI355X
+    main.train(1, n_iter)      # reference loss/Adam; one gradient all-reduce per mini-batch
+
+Differences by design:
+  * self_play(n) plays its n games side by side (G = n slots of one engine, finished slots are
+    refilled) instead of one after another. Episode e gets its own np.random stream seeded
+    SEED + e (the reference draws all games from one stream); with n == 1 the process-global
+    np.random state is used, which reproduces `np.random.seed(s); main.self_play(1)` exactly.
+  * under torch.distributed (one process per GPU) episodes are sharded e % world == rank and
+    train() all-reduces the flattened gradient (parallel.py).
+"""
+import logging
+import random
+from collections import deque
+
+import numpy as np
+
+from . import agents, parallel, utils
+from .engine import Engine
+from .evaluator import Evaluator
+
+# Game
+BOARD_SIZE = 9
+N_MCTS = 400
+TAU_THRES = 6
+SEED = 0
+PRINT_SELFPLAY = False
+
+# Net
+N_BLOCKS = 10
+IN_PLANES = 5  # history * 2 + 1
+OUT_PLANES = 128
+
+# Training
+N_SELFPLAY = 100
+TOTAL_ITER = 10000000
+MEMORY_SIZE = 30000
+N_EPOCHS = 1
+BATCH_SIZE = 32
+LR = 2e-4
+L2 = 0
+MAX_CONCURRENT = 4096   # games resident on one GPU at a time
+
+rep_memory = deque(maxlen=MEMORY_SIZE)
+cur_memory = deque()
+step = 0
+start_iter = 0
+total_epoch = 0
+result = {'Black': 0, 'White': 0, 'Draw': 0}
+
+Agent = None
+optimizer = None
+device = None
+_engine = None
+_evaluator = None
+_episodes_played = 0
+
+
+def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
+              model=None, gpu=None, noise=True):
+    """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants."""
+    global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
+    global _engine, _evaluator, _episodes_played
+    import torch
+    from .pvnet import PVNet
+    BOARD_SIZE = board_size or BOARD_SIZE
+    N_MCTS = n_mcts or N_MCTS
+    N_BLOCKS = N_BLOCKS if n_blocks is None else n_blocks
+    IN_PLANES = in_planes or IN_PLANES
+    OUT_PLANES = out_planes or OUT_PLANES
+    SEED = SEED if seed is None else seed
+    rank, world = parallel.world()
+    if gpu is None:
+        gpu = rank % max(torch.cuda.device_count(), 1)
+    device = torch.device('cuda', gpu) if torch.cuda.is_available() else torch.device('cpu')
+    random.seed(SEED)
+    np.random.seed(SEED)
+    torch.manual_seed(SEED)
+    agents.PRINT_MCTS = PRINT_SELFPLAY
+    Agent = agents.ZeroAgent(BOARD_SIZE, N_MCTS, IN_PLANES, noise=noise, device=gpu)
+    Agent.model = model if model is not None else PVNet(N_BLOCKS, IN_PLANES, OUT_PLANES, BOARD_SIZE).to(device)
+    if hasattr(Agent.model, "parameters"):
+        parallel.broadcast_parameters(Agent.model)
+        optimizer = torch.optim.Adam(Agent.model.parameters(), lr=LR, weight_decay=L2, eps=1e-6)
+    _engine = None
+    _evaluator = Evaluator(gpu)
+    _episodes_played = 0
+    return Agent
+
+
+def _get_engine(games):
+    global _engine
+    if _engine is None or _engine.G != games:
+        if _engine is not None:
+            _engine.close()
+        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device)
+    return _engine
+
+
+def self_play(n_selfplay, seeds=None):
+    """Plays n_selfplay episodes and appends their samples to cur_memory / rep_memory exactly as the
+    reference does: per episode, plies in chronological order, (state [C,B,B] f64, pi [A] f64, z)."""
+    global _episodes_played
+    if Agent is None:
+        configure()
+    if hasattr(Agent.model, "eval"):
+        Agent.model.eval()
+    rank, world = parallel.world()
+    episodes = parallel.shard_games(n_selfplay, rank, world)
+    if not episodes:
+        return
+    use_global = (n_selfplay == 1 and seeds is None and world == 1)
+    G = min(len(episodes), MAX_CONCURRENT)
+    eng = _get_engine(G)
+    eng.reset()
+
+    def seed_of(ep):
+        return int(seeds[ep]) if seeds is not None else (SEED + _episodes_played + ep) & 0xFFFFFFFF
+
+    slot_ep = np.full(G, -1, np.int64)
+    queue = list(episodes)
+    moves = {}
+    pis = {}
+    wins = {}
+    for g in range(G):
+        ep = queue.pop(0)
+        slot_ep[g] = ep
+        moves[ep], pis[ep] = [], []
+        if use_global:
+            st = np.random.get_state()
+            eng.set_rng_state(g, st[1], st[2], st[3], st[4])
+        else:
+            eng.seed(g, seed_of(ep))
+    active = np.ones(G, np.uint8)
+    while active.any():
+        ply = np.array([len(moves[e]) if e >= 0 else 0 for e in slot_ep])
+        tau = (ply < TAU_THRES).astype(np.int8)          # main.py:150-153
+        pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
+        act, win = eng.play()                             # utils.get_action + env.step
+        refill = np.zeros(G, np.uint8)
+        for g in np.nonzero(active)[0]:
+            ep = int(slot_ep[g])
+            pis[ep].append(pi[g].copy())
+            moves[ep].append(int(act[g]))
+            if win[g] != 0:
+                wins[ep] = int(win[g])
+                if queue:
+                    refill[g] = 1
+                else:
+                    active[g] = 0
+                    slot_ep[g] = -1
+        if refill.any():
+            eng.reset(refill)                             # Agent.reset() (main.py:248)
+            for g in np.nonzero(refill)[0]:
+                ep = queue.pop(0)
+                slot_ep[g] = ep
+                moves[ep], pis[ep] = [], []
+                eng.seed(int(g), seed_of(ep))
+    if use_global:
+        mt, pos, hg, gs = eng.get_rng_state(0)
+        np.random.set_state(('MT19937', mt, pos, hg, gs))
+
+    # results and samples in episode order (main.py:201-227)
+    for ep in episodes:
+        w = wins[ep]
+        if w == 1:
+            reward_black, reward_white = 1., -1.
+            result['Black'] += 1
+        elif w == 2:
+            reward_black, reward_white = -1., 1.
+            result['White'] += 1
+        else:
+            reward_black, reward_white = 0., 0.
+            result['Draw'] += 1
+        root = (0,)
+        for t, (a, p) in enumerate(zip(moves[ep], pis[ep])):
+            state = utils.get_state_pt(root, BOARD_SIZE, IN_PLANES)
+            cur_memory.append((state, p, reward_black if t % 2 == 0 else reward_white))
+            root = root + (a,)
+    _episodes_played += n_selfplay
+    Agent.reset()
+    rep_memory.extend(utils.augment_dataset(cur_memory, BOARD_SIZE))
+
+
+def train(n_epochs, n_iter):
+    """One pass over 32*len(cur_memory) samples of rep_memory, batch 32, loss = MSE(v, z) +
+    CE(pi, p), Adam (main.py:253-336). Under torch.distributed every rank draws its own batch and
+    the gradients are averaged with one all-reduce per mini-batch before optimizer.step()."""
+    global step, total_epoch
+    import torch
+    Agent.model.train()
+    n = min(BATCH_SIZE * len(cur_memory), len(rep_memory))
+    train_memory = random.sample(list(rep_memory), n)
+    losses = []
+    for epoch in range(n_epochs):
+        for i in range(0, len(train_memory), BATCH_SIZE):
+            batch = train_memory[i:i + BATCH_SIZE]
+            s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
+            pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
+            z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
+            p_batch, v_batch = Agent.model(s_batch)
+            v_loss = (v_batch - z_batch).pow(2).mean()
+            p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
+            loss = v_loss + p_loss
+            optimizer.zero_grad()
+            loss.backward()
+            parallel.allreduce_gradients(Agent.model)
+            optimizer.step()
+            step += 1
+            losses.append((loss.item(), v_loss.item(), p_loss.item()))
+            if PRINT_SELFPLAY:
+                print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *losses[-1]))
+        total_epoch += 1
+        if losses:
+            m = np.mean(np.array(losses), axis=0)
+            logging.warning('{:2} Epoch Loss: {:.4f}   Loss_V: {:.4f}   Loss_P: {:.4f}'.format(total_epoch, *m))
+    return losses
+
+
+def reset_iter(result_, cur_memory_):
+    """main.py:368-374"""
+    global total_epoch
+    result_['Black'] = 0
+    result_['White'] = 0
+    result_['Draw'] = 0
+    total_epoch = 0
+    cur_memory_.clear()

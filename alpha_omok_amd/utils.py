@@ -1,0 +1,98 @@
+"""Host-side helpers with the reference's `utils` names and results (utils.py:22-239).
+
+Inside a search these are HIP device code (tree_kernels.hip); the functions here serve the callers
+on either side of the hot path: building training samples, sampling the played move from the
+process-global numpy stream, data augmentation. Implementations are vectorised numpy.
+"""
+import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
+
+
+def legal_actions(node_id, board_size):
+    """Empty cells in the reference's order (utils.py:22-27): iteration order of a CPython set
+    difference, ascending except in deep endgames."""
+    return list(set(range(board_size * board_size)) - set(node_id[1:]))
+
+
+def get_board(node_id, board_size):
+    """+1 black / -1 white, black moves first (utils.py:171-179). float64 [B, B]."""
+    flat = np.zeros(board_size * board_size)
+    mv = np.asarray(node_id[1:], dtype=np.int64)
+    flat[mv[0::2]] = 1.0
+    flat[mv[1::2]] = -1.0
+    return flat.reshape(board_size, board_size)
+
+
+def get_turn(node_id):
+    """0 = black to move, 1 = white to move (utils.py:182-186)."""
+    return 0 if len(node_id) % 2 == 1 else 1
+
+
+def check_win(board, win_mark):
+    """0 playing / 1 black / 2 white / 3 draw (utils.py:30-59). Windows are visited row-major and
+    black is tested before white inside a window, like the reference's scan."""
+    b = np.asarray(board)
+    n = b.shape[0]
+    k = win_mark
+    if n >= k:
+        win = sliding_window_view(b, (k, k))                      # [n-k+1, n-k+1, k, k]
+        rows = win.sum(axis=3)                                    # horizontal lines
+        cols = win.sum(axis=2)                                    # vertical lines
+        d1 = np.trace(win, axis1=2, axis2=3)
+        d2 = np.trace(win[:, :, ::-1, :], axis1=2, axis2=3)
+        black = (rows == k).any(axis=2) | (cols == k).any(axis=2) | (d1 == k) | (d2 == k)
+        white = (rows == -k).any(axis=2) | (cols == -k).any(axis=2) | (d1 == -k) | (d2 == -k)
+        hit = np.flatnonzero((black | white).ravel())
+        if hit.size:
+            return 1 if black.ravel()[hit[0]] else 2
+    if np.count_nonzero(b) == n * n:
+        return 3
+    return 0
+
+
+def get_state_pt(node_id, board_size, channel_size):
+    """Network input planes, float64 [C, B, B] (utils.py:139-168): the stones of the mover of each
+    of the last C-1 plies as they stood after that ply, oldest first, then the colour plane."""
+    A = board_size * board_size
+    mv = np.asarray(node_id[1:], dtype=np.int64)
+    k = mv.size
+    planes = np.zeros((channel_size, A))
+    for j in range(channel_size - 1):
+        ply = k - j                      # X_{k-j}
+        if ply < 1:
+            continue
+        own = mv[(ply - 1) % 2:ply:2]    # moves of that ply's mover up to and including it
+        planes[channel_size - 2 - j, own] = 1.0
+    planes[channel_size - 1, :] = 1.0 if k % 2 == 0 else 0.0
+    return planes.reshape(channel_size, board_size, board_size)
+
+
+def get_action(pi):
+    """Sample the played move from np.random (utils.py:189-195). Returns (one-hot, index)."""
+    n = len(pi)
+    idx = np.random.choice(n, p=pi)
+    onehot = np.zeros(n)
+    onehot[idx] = 1
+    return onehot, idx
+
+
+def argmax_onehot(pi):
+    """Uniform choice among the maxima of pi (utils.py:198-205). Returns (one-hot, index)."""
+    best = np.flatnonzero(pi == pi.max())
+    idx = best[np.random.choice(len(best))]
+    onehot = np.zeros(len(pi))
+    onehot[idx] = 1
+    return onehot, idx
+
+
+def augment_dataset(memory, board_size):
+    """8 symmetries per sample in the reference's order r0, r0f, r1, r1f, ... (utils.py:226-239)."""
+    out = []
+    for s, pi, z in memory:
+        grid = pi.reshape(board_size, board_size)
+        for r in range(4):
+            s_r = np.rot90(s, r, axes=(1, 2))
+            p_r = np.rot90(grid, r)
+            out.append((s_r.copy(), p_r.reshape(-1).copy(), z))
+            out.append((s_r[:, :, ::-1].copy(), p_r[:, ::-1].reshape(-1).copy(), z))
+    return out

@@ -55,7 +55,25 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
     net = PVNet(n_block, 5, planes, board)
     net.load_state_dict(state_dict)
     net.eval()
-    cores = torch.get_num_threads()
+    # batch-1 convolutions do not scale to a whole server socket: pick the fastest intra-op thread
+    # count from a short calibration (the reference just uses torch's default)
+    probe = torch.zeros((1, 5, board, board))
+    best = (None, 1e9)
+    for nt in sorted({1, 4, 8, 16, 32, min(64, os.cpu_count() or 1)}):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            for _ in range(3):
+                net(probe)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                net(probe)
+            dt = (time.perf_counter() - t0) / 20
+        if dt < best[1]:
+            best = (nt, dt)
+    torch.set_num_threads(best[0])
+    cores = best[0]
 
     def ev(moves, planes_, sim):
         with torch.no_grad():

@@ -1,0 +1,140 @@
+"""-m gpu: the reference-shaped Python surface (agents.ZeroAgent, main.self_play) on the HIP engine
+against golden vectors captured from the reference and against the oracle."""
+import numpy as np
+import pytest
+
+import pvnet_weights
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class StubModel:
+    """Agent.model stand-in (any callable works): the oracle's exact-arithmetic stub, batch-capable."""
+
+    def __init__(self, oracle, mode):
+        self.oracle, self.mode = oracle, mode
+
+    def eval(self):
+        return self
+
+    def __call__(self, x):
+        import torch
+        xs = x.detach().cpu().numpy().astype(np.float32)
+        ps, vs = zip(*(self.oracle.stub_eval(xs[i], self.mode) for i in range(xs.shape[0])))
+        return torch.from_numpy(np.stack(ps)), torch.from_numpy(np.array(vs, np.float32))
+
+
+def test_zero_agent_matches_reference_under_numpy_seed(oracle):
+    """np.random.seed(s); ZeroAgent.get_pi; utils.get_action -- the reference's own call sequence
+    (main.py:155-171) -- reproduces the reference's pi / visit / policy / move and leaves the
+    process-global numpy stream where the reference leaves it (gv5 captured from the reference)."""
+    from alpha_omok_amd import agents, utils
+    agents.PRINT_MCTS = False
+    g = load_golden("gv5_tree_stub")
+    for ci in (0, 4, 10, 13):
+        B, S, mode, seed, plies, tau_thres, noise, nrec, win = g["meta"][ci].tolist()
+        agent = agents.ZeroAgent(B, S, 5, noise=bool(noise))
+        agent.model = StubModel(oracle, mode)
+        np.random.seed(seed)
+        root_id = (0,)
+        for t in range(nrec):
+            pi = agent.get_pi(root_id, 1 if t < tau_thres else 0)
+            np.testing.assert_array_equal(pi, g["c%d_pi" % ci][t])
+            np.testing.assert_array_equal(agent.get_visit(), g["c%d_visit" % ci][t])
+            np.testing.assert_array_equal(agent.get_policy(), g["c%d_policy" % ci][t])
+            assert agent.is_real_root == (t == 0)
+            _, a = utils.get_action(pi)
+            assert a == int(g["c%d_action" % ci][t])
+            assert np.random.get_state()[2] == int(g["c%d_mt_pos" % ci][t])
+            root_id = root_id + (int(a),)
+        assert agent.get_name() == "ZeroAgent" and agent.root_id == root_id[:-1]
+        agent.reset()
+        assert agent.root_id is None
+
+
+def test_zero_agent_native_pvnet_path():
+    """A PVNet-shaped Agent.model runs on the MFMA forward; get_pv matches the torch module."""
+    import torch
+    from alpha_omok_amd import agents
+    from alpha_omok_amd.pvnet import PVNet
+    agents.PRINT_MCTS = False
+    B, S = 9, 48
+    model = PVNet(2, 5, 64, B)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in pvnet_weights.make_state_dict(2, 5, 64, B, 9).items()})
+    model = model.cuda().eval()
+    agent = agents.ZeroAgent(B, S, 5, noise=True)
+    agent.model = model
+    np.random.seed(3)
+    root = (0,)
+    for t in range(3):
+        pi = agent.get_pi(root, 1)
+        assert agent.get_visit().sum() == (S if t == 0 else agent.get_visit().sum())
+        assert abs(pi.sum() - 1) < 1e-12
+        root = root + (int(np.argmax(pi)),)
+    assert agent._evaluator.native_net(model, B, 5) is not None
+    p, v = agent.get_pv(root)
+    with torch.no_grad():
+        from alpha_omok_amd import utils
+        rp, rv = model(torch.from_numpy(utils.get_state_pt(root, B, 5)[None]).float().cuda())
+    assert np.abs(p - rp.cpu().numpy()[0]).max() < 1e-4 and abs(float(v) - float(rv[0])) < 1e-4
+    assert p.dtype == np.float32
+
+
+def test_self_play_single_episode_matches_reference_memory(oracle):
+    """np.random.seed(s); main.self_play(1) -> cur_memory / rep_memory / result as the reference
+    produced them (tests/golden/gv9, captured from main.self_play with the same stub model)."""
+    import alpha_omok_amd.main as main
+    g = load_golden("gv9_self_play_memory")
+    for ci in range(2):
+        B, S, mode, seed = g["c%d_cfg" % ci].tolist()
+        main.PRINT_SELFPLAY = False
+        main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, mode), seed=0)
+        main.cur_memory.clear()
+        main.rep_memory.clear()
+        main.reset_iter(main.result, main.cur_memory)
+        np.random.seed(seed)
+        main.self_play(1)
+        cm = list(main.cur_memory)
+        assert len(cm) == len(g["c%d_z" % ci])
+        np.testing.assert_array_equal(np.stack([m[0] for m in cm]).astype(np.float32), g["c%d_state" % ci])
+        np.testing.assert_array_equal(np.stack([m[1] for m in cm]), g["c%d_pi" % ci])
+        np.testing.assert_array_equal(np.array([m[2] for m in cm]), g["c%d_z" % ci])
+        assert [main.result[k] for k in ("Black", "White", "Draw")] == g["c%d_result" % ci].tolist()
+        assert len(main.rep_memory) == int(g["c%d_rep_len" % ci])
+        rm = list(main.rep_memory)[:16]
+        np.testing.assert_array_equal(np.stack([m[1] for m in rm]), g["c%d_rep_pi_head" % ci])
+        np.testing.assert_array_equal(np.stack([m[0] for m in rm]).astype(np.float32), g["c%d_rep_state_head" % ci])
+        assert cm[0][0].dtype == np.float64 and cm[0][1].dtype == np.float64
+
+
+def test_self_play_concurrent_episodes_match_oracle_games(oracle):
+    """n episodes side by side (with slot refill) == n sequential oracle games with the same seeds."""
+    import alpha_omok_amd.main as main
+    B, S, mode, n = 9, 40, 1, 7
+    main.MAX_CONCURRENT = 4                      # forces refills: 7 episodes through 4 slots
+    main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, mode), seed=123)
+    main.cur_memory.clear()
+    main.rep_memory.clear()
+    main.reset_iter(main.result, main.cur_memory)
+    main.self_play(n)
+    main.MAX_CONCURRENT = 4096
+    cm = list(main.cur_memory)
+    ag = oracle.Agent(B, S, 5, noise=True, evaluator="stub%d" % mode)
+    off = 0
+    res = {1: 0, 2: 0, 3: 0}
+    for ep in range(n):
+        moves, pis, vis, win = ag.self_play_game(123 + ep, main.TAU_THRES)
+        res[win] += 1
+        zb = {1: 1.0, 2: -1.0, 3: 0.0}[win]
+        root = (0,)
+        for t in range(len(moves)):
+            s, pi, z = cm[off + t]
+            np.testing.assert_array_equal(pi, pis[t], err_msg="episode %d ply %d" % (ep, t))
+            np.testing.assert_array_equal(s.astype(np.float32), oracle.get_state_pt(list(root)[1:], B, 5))
+            assert z == (zb if t % 2 == 0 else -zb)
+            root = root + (int(moves[t]),)
+        off += len(moves)
+    assert off == len(cm)
+    assert [main.result[k] for k in ("Black", "White", "Draw")] == [res[1], res[2], res[3]]
+    assert len(main.rep_memory) == min(8 * len(cm), main.MEMORY_SIZE)

@@ -1,0 +1,177 @@
+"""CPU: host-side mirror of the reference interface (alpha_omok_amd.utils / pvnet / parallel /
+main.train) against the golden vectors, plus the multi-process (gloo, world_size 2) gradient
+all-reduce path."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+import pvnet_weights
+from conftest import REPO, load_golden
+
+
+def test_utils_check_win_golden():
+    from alpha_omok_amd import utils
+    g = load_golden("gv1_check_win")
+    for b, (n, k), w in zip(g["boards"], g["size_mark"], g["win"]):
+        assert utils.check_win(b[:n, :n].astype(float), int(k)) == int(w)
+
+
+def test_utils_planes_board_turn_golden():
+    from alpha_omok_amd import utils
+    g = load_golden("gv3_state_planes")
+    for i in range(int(g["count"])):
+        m = g["m%d" % i]
+        B, C, nid = int(m[0]), int(m[1]), (0,) + tuple(int(x) for x in m[2:])
+        s = utils.get_state_pt(nid, B, C)
+        assert s.dtype == np.float64 and s.shape == (C, B, B)
+        np.testing.assert_array_equal(s.astype(np.float32), g["s%d" % i])
+        np.testing.assert_array_equal(utils.get_board(nid, B).astype(np.int8), g["b%d" % i])
+        assert utils.get_turn(nid) == int(g["t%d" % i])
+
+
+def test_utils_legal_order_golden():
+    from alpha_omok_amd import utils
+    g = load_golden("gv2_legal_order")
+    for B, mv, order in list(zip(g["board"], g["moves"], g["order"]))[::7]:
+        nid = (0,) + tuple(int(x) for x in mv[mv >= 0])
+        assert utils.legal_actions(nid, int(B)) == order[order >= 0].tolist()
+
+
+def test_utils_augment_golden():
+    from alpha_omok_amd import utils
+    g = load_golden("gv8_augment")
+    for i, B in enumerate((3, 9)):
+        aug = utils.augment_dataset([(g["s%d" % i], g["pi%d" % i], 1.0)], B)
+        assert len(aug) == 8
+        np.testing.assert_array_equal(np.stack([a[0] for a in aug]), g["as%d" % i])
+        np.testing.assert_array_equal(np.stack([a[1] for a in aug]), g["api%d" % i])
+
+
+def test_utils_sampling_uses_numpy_stream_like_reference(oracle):
+    from alpha_omok_amd import utils
+    rs = np.random.RandomState(4)
+    for seed in (0, 5, 99):
+        pi = rs.dirichlet(np.ones(81))
+        np.random.seed(seed)
+        r = oracle.Rng(seed)
+        _, a = utils.get_action(pi)
+        assert a == r.choice_p(pi)
+        vis = rs.randint(0, 4, 81).astype(float)
+        _, b = utils.argmax_onehot(vis / vis.sum())
+        k = int((vis == vis.max()).sum())
+        assert b == np.flatnonzero(vis == vis.max())[r.choice(k)]
+        assert np.random.get_state()[2] == r.pos
+
+
+def test_pvnet_state_dict_wire_format_and_forward_golden():
+    import torch
+    from alpha_omok_amd.pvnet import PVNet, looks_like_pvnet
+    g = load_golden("gv7_pvnet_forward")
+    for i in range(int(g["count"])):
+        nb, B, planes, wseed = g["cfg%d" % i].tolist()
+        sd = pvnet_weights.make_state_dict(nb, 5, planes, B, wseed)
+        net = PVNet(nb, 5, planes, B)
+        assert set(net.state_dict().keys()) == set(sd.keys())
+        for k, v in net.state_dict().items():
+            assert tuple(v.shape) == sd[k].shape, k
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        assert looks_like_pvnet(net) == (nb, 5, planes, B)
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(g["x%d" % i]))
+        assert np.abs(p.numpy() - g["p%d" % i]).max() < 1e-5
+        assert np.abs(v.numpy() - g["v%d" % i]).max() < 1e-5
+
+
+def test_train_step_golden():
+    """main.train's loss and Adam step (main.py:85,294-305) against the reference's own numbers."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    g = load_golden("gv10_train_step")
+    nb, B, planes, wseed = g["cfg"].tolist()
+    net = PVNet(nb, 5, planes, B)
+    sd = pvnet_weights.make_state_dict(nb, 5, planes, B, wseed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, weight_decay=0, eps=1e-6)
+    s, pi, z = (torch.from_numpy(g[k]) for k in ("s", "pi", "z"))
+    p, v = net(s)
+    v_loss = (v - z).pow(2).mean()
+    p_loss = -(pi * p.log()).sum(dim=-1).mean()
+    assert abs(v_loss.item() - float(g["v_loss"])) < 1e-5
+    assert abs(p_loss.item() - float(g["p_loss"])) < 1e-5
+    opt.zero_grad()
+    (v_loss + p_loss).backward()
+    grads = dict(net.named_parameters())
+    for key in g.files:
+        if key.startswith("grad__"):
+            assert np.abs(grads[key[6:]].grad.numpy() - g[key]).max() < 1e-5, key
+    opt.step()
+    after = net.state_dict()
+    for key in g.files:
+        if key.startswith("after__"):
+            assert np.abs(after[key[7:]].numpy() - g[key]).max() < 1e-5, key
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import pvnet_weights as pw
+    from alpha_omok_amd import parallel
+    from alpha_omok_amd.pvnet import PVNet
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    torch.manual_seed(100 + rank)                      # deliberately different initial weights
+    net = PVNet(1, 5, 32, 9)
+    net.eval()                                         # BN in eval: grads add up across shards
+    ref_sd = {k: torch.from_numpy(v) for k, v in pw.make_state_dict(1, 5, 32, 9, 3).items()}
+    if rank == 0:
+        net.load_state_dict(ref_sd)
+    parallel.broadcast_parameters(net)                 # rank 0's weights everywhere
+    same = all(torch.equal(net.state_dict()[k], ref_sd[k]) for k in ref_sd if ref_sd[k].is_floating_point())
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy((rs.rand(8, 5, 9, 9) < 0.3).astype(np.float32))
+    pi = torch.from_numpy(rs.dirichlet(np.ones(81), size=8).astype(np.float32))
+    z = torch.from_numpy(rs.choice([-1.0, 0.0, 1.0], size=8).astype(np.float32))
+    sl = slice(rank * 4, rank * 4 + 4)
+    p, v = net(x[sl])
+    loss = (v - z[sl]).pow(2).mean() - (pi[sl] * p.log()).sum(-1).mean()
+    loss.backward()
+    n = parallel.allreduce_gradients(net)
+    flat = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
+    torch.save(dict(same=same, n=n, grad=flat, shard=parallel.shard_games(10, rank, world)), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_allreduce(tmp_path):
+    """N>1 path on CPU: mean of the per-rank gradients == gradient of the full batch; broadcast makes
+    the weights identical; games shard g % world."""
+    import torch
+    import torch.multiprocessing as mp
+    from alpha_omok_amd.pvnet import PVNet
+    port = 29500 + random.randint(0, 2000)
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0["same"] and r1["same"]
+    assert torch.equal(r0["grad"], r1["grad"])
+    assert r0["shard"] == [0, 2, 4, 6, 8] and r1["shard"] == [1, 3, 5, 7, 9]
+    net = PVNet(1, 5, 32, 9)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in pvnet_weights.make_state_dict(1, 5, 32, 9, 3).items()})
+    net.eval()
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy((rs.rand(8, 5, 9, 9) < 0.3).astype(np.float32))
+    pi = torch.from_numpy(rs.dirichlet(np.ones(81), size=8).astype(np.float32))
+    z = torch.from_numpy(rs.choice([-1.0, 0.0, 1.0], size=8).astype(np.float32))
+    p, v = net(x)
+    ((v - z).pow(2).mean() - (pi * p.log()).sum(-1).mean()).backward()
+    full = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
+    assert r0["n"] == full.numel()
+    assert (r0["grad"] - full).abs().max().item() < 1e-5
