@@ -162,7 +162,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &p.rstatus, G) || dev_alloc(e, &p.leaf_status, G) || dev_alloc(e, &p.path_len, G) ||
         dev_alloc(e, &p.path_node, static_cast<size_t>(G) * p.maxd) ||
         dev_alloc(e, &p.path_edge, static_cast<size_t>(G) * p.maxd) || dev_alloc(e, &p.leaf_pos, G) ||
-        dev_alloc(e, &p.err, G) || dev_alloc(e, &p.stats, 4) ||
+        dev_alloc(e, &p.err, G) || dev_alloc(e, &p.stats, static_cast<size_t>(G) * 4) ||
         dev_alloc(e, &p.out_pi, static_cast<size_t>(G) * A) || dev_alloc(e, &p.out_visit, static_cast<size_t>(G) * A) ||
         dev_alloc(e, &p.out_policy, static_cast<size_t>(G) * A) || dev_alloc(e, &p.action, G) ||
         dev_alloc(e, &p.win, G) || dev_alloc(e, &e->d_active, G) || dev_alloc(e, &e->d_tau, G) ||
@@ -206,7 +206,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     }
     AO_HIP(e, hipMemcpyAsync(p.mt, e->h_mt, sizeof(uint32_t) * 624 * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(p.mtpos, e->h_pos, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
-    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 4, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned) * 4 * G, e->stream));
     AO_HIP(e, hipMemsetAsync(p.noise_buf, 0, sizeof(double) * G * Ap, e->stream));
     ao::launch_reset(p, nullptr, e->stream);
     AO_HIP(e, hipStreamSynchronize(e->stream));
@@ -388,7 +388,7 @@ int ao_begin_move(ao_engine* e, const uint8_t* active) {
     AO_HIP(e, hipMemcpyAsync(p.sims_target, target, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(p.gflags, flags, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(e->d_active, e->active.data(), G, hipMemcpyHostToDevice, e->stream));
-    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 4, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned) * 4 * G, e->stream));
     ao::launch_begin_move(p, e->stream);
     // the pinned staging buffers are reused by the next call: make sure the copies are done
     AO_HIP(e, hipStreamSynchronize(e->stream));
@@ -563,9 +563,12 @@ int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries)
 
 int ao_search_stats(ao_engine* e, int64_t* levels, int64_t* ties, int64_t* terminal, int64_t* evaluated) {
     AO_HIP(e, hipSetDevice(e->cfg.device));
-    unsigned long long h[4];
-    AO_HIP(e, hipMemcpyAsync(h, e->tp.stats, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    std::vector<unsigned> per(static_cast<size_t>(e->G) * 4);
+    AO_HIP(e, hipMemcpyAsync(per.data(), e->tp.stats, sizeof(unsigned) * per.size(), hipMemcpyDeviceToHost, e->stream));
     AO_HIP(e, hipStreamSynchronize(e->stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    for (int g = 0; g < e->G; ++g)
+        for (int k = 0; k < 4; ++k) h[k] += per[static_cast<size_t>(g) * 4 + k];
     if (levels) *levels = static_cast<int64_t>(h[0]);
     if (ties) *ties = static_cast<int64_t>(h[1]);
     if (terminal) *terminal = static_cast<int64_t>(h[2]);

@@ -67,7 +67,7 @@ struct TreeParams {
     // per simulation scratch
     int32_t* leaf_status; int32_t* path_len; int32_t* path_node; int16_t* path_edge; Pos* leaf_pos;
     int32_t* err;
-    unsigned long long* stats;  // [4]: levels, ties, terminal leaves, evaluated leaves
+    unsigned* stats;      // [G][4] per game: levels, ties, terminal leaves, evaluated leaves
     const double* sqrt_lut; int sqrt_lut_n;
     // evaluation batch
     float* batch_il;      // interleaved [grp][cell][cq][il_group][4] (native network input) or null

@@ -373,10 +373,11 @@ __global__ __launch_bounds__(64) void k_select(TreeParams p) {
     if (lane == 0) {
         p.leaf_status[g] = status;
         p.path_len[g] = depth;
-        atomicAdd(&p.stats[0], static_cast<unsigned long long>(levels));
-        if (ties) atomicAdd(&p.stats[1], static_cast<unsigned long long>(ties));
-        if (status == LS_TERMINAL) atomicAdd(&p.stats[2], 1ull);
-        else atomicAdd(&p.stats[3], 1ull);
+        // per-game counters (a shared word would serialise 4 x G atomics per simulation)
+        unsigned* st = p.stats + static_cast<size_t>(g) * 4;
+        st[0] += levels;
+        st[1] += ties;
+        st[(status == LS_TERMINAL) ? 2 : 3] += 1u;
     }
     mt.close();
 }

@@ -185,3 +185,68 @@ def test_set_root_semantics(oracle):
         mt, pos, hg, gs = eng.get_rng_state(0)
         assert pos == ag.rng.pos
     eng.close()
+
+
+def test_full_size_properties_and_sampled_oracle_parity(oracle):
+    """BASELINE configs[2] size (4096 games x 400 sims, native PVNet, group-resident trunk):
+    size-independent properties for every game + bit-exact oracle replay of a few sampled games."""
+    import torch
+    import pvnet_weights
+    from alpha_omok_amd.engine import Engine, Net
+    B, S, G = 9, 400, 4096
+    net = Net(4, 5, 128, B, 0)
+    net.load_state_dict(pvnet_weights.make_state_dict(4, 5, 128, B, 77))
+    eng = Engine(B, S, 5, games=G, noise=True)
+    seeds = np.arange(9000, 9000 + G, dtype=np.uint32)
+    eng.seed_all(seeds)
+    sample = [0, 1, 17, 2048, 4095]
+    planes = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
+    rec = {g: [] for g in sample}
+    eng.begin_move()
+    while eng.sims_left() > 0:
+        eng.collect_leaves(planes.data_ptr())
+        eng.sync()
+        p, v = net(planes)                       # ao_net_forward: same kernels as ao_search
+        torch.cuda.synchronize()
+        hp, hv = p[sample].cpu().numpy(), v[sample].cpu().numpy()
+        for i, g in enumerate(sample):
+            rec[g].append((hp[i].copy(), hv[i].copy()))
+        eng.apply_evals(p.data_ptr(), v.data_ptr())
+    tau = np.ones(G, np.int8)
+    pi, vis, pol = eng.end_move(tau)
+    # properties that hold for every game regardless of size
+    assert np.all(vis.sum(axis=1) == S)                      # fresh root: S+1 sims, S child visits
+    assert np.all(vis == np.round(vis)) and np.all(vis >= 0)
+    assert np.abs(pi.sum(axis=1) - 1).max() < 1e-12
+    assert np.abs(pol.sum(axis=1) - 1).max() < 1e-9          # renormalised priors mixed with Dirichlet noise
+    assert np.all(pol > 0)                                   # every cell is legal on the empty board
+    st = eng.search_stats()
+    assert st["evaluated"] + st["terminal"] == G * (S + 1) and st["terminal"] == 0
+    assert 1.0 < st["levels"] / (G * (S + 1)) < 3.0
+    act, win = eng.play()
+    assert np.all(win == 0) and np.all((act >= 0) & (act < B * B))
+    assert np.all(vis[np.arange(G), act] > 0)                # the sampled move was visited
+    # sampled games against the oracle, bit for bit
+    for g in sample:
+        cur = [0]
+
+        def replay(moves, pl, sim, g=g, cur=cur):
+            i = cur[0]
+            cur[0] += 1
+            return rec[g][i]
+
+        ag = oracle.Agent(B, S, 5, noise=True, evaluator=replay)
+        ag.seed(int(seeds[g]))
+        opi, ovis, opol = ag.get_pi((0,), 1)
+        np.testing.assert_array_equal(vis[g], ovis, err_msg="game %d" % g)
+        np.testing.assert_array_equal(pol[g], opol)
+        assert act[g] == ag.rng.choice_p(opi)
+    # determinism: a second engine with the same seeds and the fused path gives the same visits
+    eng2 = Engine(B, S, 5, games=G, noise=True)
+    eng2.seed_all(seeds)
+    pi2, vis2, pol2 = eng2.search(net, tau=tau)
+    np.testing.assert_array_equal(vis2, vis)
+    np.testing.assert_array_equal(pol2, pol)
+    eng.close()
+    eng2.close()
+    net.close()
