@@ -209,6 +209,11 @@ struct TrunkArgs {
     float4* bufA;       // [grp][A][CQ][16]
     float4* bufB;
     int nlayers, cq0, CQ, COUT;
+    int cq0_real;       // channel quads of the input that are not padding
+    // heads (model.py:34-73), run by the same workgroup once its trunk is done
+    const float *w3, *sc3, *sh3, *wp_t, *bp, *w1_t, *b1, *w2, *b2;
+    float* policy;      // [boards][A]
+    float* value;       // [boards]
     TrunkLayer layers[kMaxTrunkLayers];
 };
 
@@ -224,8 +229,8 @@ struct TrunkArgs {
 template <int BW, int XT, int TPW>
 __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
                                             const float4* __restrict__ wt, const float4* __restrict__ scp,
-                                            const float4* __restrict__ shp, const bool RES, int cqi, int COUT,
-                                            size_t gbase, int ct0, int kq, int b) {
+                                            const float4* __restrict__ shp, const bool RES, int cqi, int cq_real,
+                                            int COUT, size_t gbase, int ct0, int kq, int b) {
     constexpr int NXT = (BW + XT - 1) / XT;
     constexpr int NX = XT + 2;
     constexpr int GB = 16;
@@ -298,17 +303,19 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
             }
         };
         // one step: input row yi, channel group of X; (nyi, ncq) is the step after it
-        auto step = [&](const Frag (&X)[NX], Frag (&Xn)[NX], int yi, int nyi, int ncq) {
+        // `live` is false for a k-step whose 16 input channels are all padding (conv1: 5 planes in
+        // a 32-channel slab): its loads are issued to keep the stream uniform, its MFMAs are not.
+        auto step = [&](const Frag (&X)[NX], Frag (&Xn)[NX], int yi, int nyi, int ncq, bool live) {
             // sched_barrier keeps each weight re-load BELOW the last MFMA that reads the registers it
             // overwrites; hoisted above, it would need a second copy of the weight fragments
             load_x(nyi, ncq, Xn);
-            if (yi + 1 < BW) taps(X, 0, acc2);  // dy = 0 -> output row yi + 1
+            if (live && yi + 1 < BW) taps(X, 0, acc2);  // dy = 0 -> output row yi + 1
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 0);
-            taps(X, 1, acc1);                   // dy = 1 -> output row yi
+            if (live) taps(X, 1, acc1);                 // dy = 1 -> output row yi
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 1);
-            if (yi >= 1) taps(X, 2, acc0);      // dy = 2 -> output row yi - 1
+            if (live && yi >= 1) taps(X, 2, acc0);      // dy = 2 -> output row yi - 1
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 2);
         };
@@ -362,15 +369,97 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
         load_w(0, 2);
         for (int yi = 0; yi < BW; ++yi) {
             for (int cqg = 0; cqg < ncqg; cqg += 2) {
-                step(xa, xb, yi, yi, cqg + 1);
+                step(xa, xb, yi, yi, cqg + 1, cqg * 4 < cq_real);
                 const bool same = cqg + 2 < ncqg;
                 const bool last = !same && (yi + 1 >= BW);  // end of the layer: harmless re-load
-                step(xb, xa, yi, same || last ? yi : yi + 1, same ? cqg + 2 : (last ? cqg + 1 : 0));
+                step(xb, xa, yi, same || last ? yi : yi + 1, same ? cqg + 2 : (last ? cqg + 1 : 0),
+                     (cqg + 1) * 4 < cq_real);
             }
             if (yi >= 1) epilogue(yi - 1);
             slide();
         }
         epilogue(BW - 1);  // after the last slide the bottom row sits in acc0
+    }
+}
+
+// Policy and value heads of one 16-board group inside the resident kernel (model.py:34-73):
+// 1x1 convs + BN + ReLU into LDS (flatten order c*A + cell, as the reference's .view), then one
+// wave per board: policy_fc + softmax, value_fc1 + ReLU + value_fc2 + tanh.
+template <int BW>
+__device__ __forceinline__ void trunk_heads(const TrunkArgs& a, const float4* act, size_t gbase, int grp) {
+    constexpr int A = BW * BW;
+    constexpr int GB = 16;
+    constexpr int NA = (A + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float s_heads[];
+    const int planes = a.COUT, CQ = a.CQ;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    float* s_w3 = s_heads;              // [3][planes]
+    float* s_h = s_w3 + 3 * planes;     // [16 boards][3][A]
+    for (int i = tid; i < 3 * planes; i += nthreads) s_w3[i] = a.w3[i];
+    __syncthreads();
+    {
+        const int b = tid & 15;
+        for (int cell = tid >> 4; cell < A; cell += nthreads >> 4) {
+            const float4* xp = act + ((gbase + cell) * CQ) * GB + b;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            for (int cq = 0; cq < CQ; ++cq) {
+                const float4 x = xp[static_cast<size_t>(cq) * GB];
+                const float* w0 = s_w3 + 4 * cq;
+                const float* w1 = s_w3 + planes + 4 * cq;
+                const float* w2 = s_w3 + 2 * planes + 4 * cq;
+                a0 = fmaf(x.x, w0[0], a0); a0 = fmaf(x.y, w0[1], a0); a0 = fmaf(x.z, w0[2], a0); a0 = fmaf(x.w, w0[3], a0);
+                a1 = fmaf(x.x, w1[0], a1); a1 = fmaf(x.y, w1[1], a1); a1 = fmaf(x.z, w1[2], a1); a1 = fmaf(x.w, w1[3], a1);
+                a2 = fmaf(x.x, w2[0], a2); a2 = fmaf(x.y, w2[1], a2); a2 = fmaf(x.z, w2[2], a2); a2 = fmaf(x.w, w2[3], a2);
+            }
+            float* h = s_h + b * 3 * A + cell;
+            h[0] = fmaxf(fmaf(a0, a.sc3[0], a.sh3[0]), 0.f);
+            h[A] = fmaxf(fmaf(a1, a.sc3[1], a.sh3[1]), 0.f);
+            h[2 * A] = fmaxf(fmaf(a2, a.sc3[2], a.sh3[2]), 0.f);
+        }
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    for (int bb = wave; bb < GB; bb += nw) {
+        const float* h = s_h + bb * 3 * A;
+        const size_t board = static_cast<size_t>(grp) * GB + bb;
+        float lg[NA];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const int o = lane + 64 * c;
+            lg[c] = -3.0e38f;
+            if (o < A) {
+                float acc = a.bp[o];
+                for (int j = 0; j < 2 * A; ++j) acc = fmaf(a.wp_t[static_cast<size_t>(j) * A + o], h[j], acc);
+                lg[c] = acc;
+                mx = fmaxf(mx, acc);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const int o = lane + 64 * c;
+            lg[c] = (o < A) ? expf(lg[c] - mx) : 0.f;
+            sum += lg[c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            const int o = lane + 64 * c;
+            if (o < A) a.policy[board * A + o] = lg[c] / sum;
+        }
+        float part = 0.f;
+        for (int o = lane; o < planes; o += 64) {
+            float acc = a.b1[o];
+            for (int j = 0; j < A; ++j) acc = fmaf(a.w1_t[static_cast<size_t>(j) * planes + o], h[2 * A + j], acc);
+            part = fmaf(a.w2[o], fmaxf(acc, 0.f), part);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) a.value[board] = tanhf(part + a.b2[0]);
     }
 }
 
@@ -393,13 +482,15 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
         float4* dst = (l == 0) ? a.bufA : ((l & 1) ? a.bufB : a.bufA);
         // even l > 0: second conv of a ResBlock, + x (held in bufA = dst)
         trunk_layer<BW, XT, TPW>(src, dst, a.layers[l].w, a.layers[l].sc, a.layers[l].sh, l > 0 && (l & 1) == 0,
-                                 l == 0 ? a.cq0 : a.CQ, a.COUT, gbase, ct0, kq, b);
+                                 l == 0 ? a.cq0 : a.CQ, l == 0 ? a.cq0_real : a.CQ, a.COUT, gbase, ct0, kq, b);
         // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
         // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // the trunk output of this group (bufA: nlayers is odd) is still in this XCD's L2: run both heads
+    trunk_heads<BW>(a, a.bufA, gbase, grp);
 }
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
@@ -643,7 +734,8 @@ static void launch_conv(ao_net* n, int layer, const float* in, int cqi, const fl
 }
 
 template <int BW>
-static void launch_trunk16(ao_net* n, const float* in_il, int groups, hipStream_t s) {
+static void launch_trunk16(ao_net* n, const float* in_il, int groups, float* policy, float* value,
+                           hipStream_t s) {
     constexpr int XT = (BW <= 9) ? BW : 5;  // cells per window row: 3 rows x XT x 2 tiles of accumulators
     TrunkArgs a;
     a.in0 = reinterpret_cast<const float4*>(in_il);
@@ -651,8 +743,13 @@ static void launch_trunk16(ao_net* n, const float* in_il, int groups, hipStream_
     a.bufB = reinterpret_cast<float4*>(n->act_t);
     a.nlayers = 1 + 2 * n->nb;
     a.cq0 = n->nchq16;
+    a.cq0_real = (n->C + 3) / 4;
     a.CQ = n->CQ;
     a.COUT = n->planes;
+    a.w3 = n->head_w3; a.sc3 = n->head_sc3; a.sh3 = n->head_sh3;
+    a.wp_t = n->wp_t; a.bp = n->bp; a.w1_t = n->w1_t; a.b1 = n->b1; a.w2 = n->w2; a.b2 = n->b2;
+    a.policy = policy;
+    a.value = value;
     for (int l = 0; l < a.nlayers; ++l) {
         a.layers[l].w = reinterpret_cast<const float4*>(l == 0 ? n->conv0_w16 : n->conv_w[l]);
         a.layers[l].sc = reinterpret_cast<const float4*>(n->conv_sc[l]);
@@ -701,12 +798,14 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
         }                                                                                                    \
         lds_attr_done[W] = true;                                                                             \
-        launch_trunk16<W>(n, in_il, groups, s);                                                              \
+        launch_trunk16<W>(n, in_il, groups, policy, value, s);                                               \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
             AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
         }
+        NET_HIP(n, hipGetLastError());
+        return 0;  // the heads ran inside the resident kernel
     } else {
         auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
             switch (n->B) {
