@@ -1,0 +1,75 @@
+"""-m gpu: edge cases of the hot path -- other history depths (IN_PLANES = 3, 7), noise off,
+error paths that must fail loudly instead of corrupting a search."""
+import numpy as np
+import pytest
+
+from gpu_helpers import HostEvalRunner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("inplanes,board,noise", [(3, 9, True), (7, 9, True), (9, 5, True), (5, 9, False)])
+def test_other_history_depths_and_noise_off(oracle, inplanes, board, noise):
+    """get_state_pt is generic in the channel count (main.py:34 IN_PLANES = 2*history+1); the stub
+    evaluator hashes every plane, so a wrong plane changes the visit counts."""
+    from alpha_omok_amd.engine import Engine
+    S, G = 50, 3
+    eng = Engine(board, S, inplanes, games=G, noise=noise)
+    run = HostEvalRunner(eng)
+    seeds = [31, 32, 33]
+    eng.seed_all(seeds)
+    ags = [oracle.Agent(board, S, inplanes, noise=noise, evaluator="stub1") for _ in range(G)]
+    for g in range(G):
+        ags[g].seed(seeds[g])
+    roots = [(0,)] * G
+    for t in range(7):
+        pi, vis, pol = run.move(lambda g, sim, pl: oracle.stub_eval(pl, 1), tau=np.ones(G, np.int8))
+        act, win = eng.play()
+        for g in range(G):
+            opi, ovis, opol = ags[g].get_pi(roots[g], 1)
+            np.testing.assert_array_equal(vis[g], ovis, err_msg="C=%d game %d ply %d" % (inplanes, g, t))
+            np.testing.assert_array_equal(pol[g], opol)
+            assert act[g] == ags[g].rng.choice_p(opi)
+            roots[g] = roots[g] + (int(act[g]),)
+        if (win != 0).any():
+            break
+    eng.close()
+
+
+def test_node_cap_overflow_fails_loudly(oracle):
+    from alpha_omok_amd.engine import Engine, EngineError
+    eng = Engine(9, 40, 5, games=2, noise=True, node_cap=42)   # room for ONE fresh search only
+    run = HostEvalRunner(eng)
+    ev = lambda g, sim, pl: oracle.stub_eval(pl, 1)
+    run.move(ev)
+    eng.play()
+    with pytest.raises(EngineError, match="node_cap"):
+        for _ in range(6):
+            run.move(ev)
+            eng.play()
+    eng.close()
+
+
+def test_illegal_root_id_is_rejected():
+    from alpha_omok_amd.engine import Engine, EngineError
+    eng = Engine(9, 10, 5, games=1)
+    with pytest.raises(EngineError, match="illegal move"):
+        eng.set_root(0, [3, 4, 3])          # cell 3 twice
+    with pytest.raises(EngineError, match="illegal move"):
+        eng.set_root(0, [3, 81])            # outside the board
+    assert eng.set_root(0, [3, 4]) == 0     # still usable afterwards (fresh tree)
+    eng.close()
+
+
+def test_protocol_misuse_is_rejected():
+    from alpha_omok_amd.engine import Engine, EngineError
+    eng = Engine(3, 5, 5, games=1)
+    with pytest.raises(EngineError):
+        eng.play()                          # ao_play without ao_end_move
+    with pytest.raises(EngineError):
+        eng.collect_leaves(None)            # outside begin/end
+    with pytest.raises(EngineError):
+        Engine(9, 10, 4, games=1)           # even IN_PLANES
+    with pytest.raises(EngineError):
+        Engine(16, 10, 5, games=1)          # board too large
+    eng.close()
