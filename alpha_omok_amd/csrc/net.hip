@@ -493,6 +493,61 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
     trunk_heads<BW>(a, a.bufA, gbase, grp);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Small batches (a drop-in ZeroAgent has ONE game): boards cannot fill the MFMA N dimension, so
+// the CELLS of one board do:   D[cout 16][cell 16] += Wt[cout 16][k 4] * X[k 4][cell 16]
+// on the plain per-board NHWC layout act[board][cell][channel]. One wave per (16 cells, 16 output
+// channels, board): a 9x9x128 layer is 48 independent waves of 288 MFMAs (~4 us) instead of nine
+// workgroups of ~130 us, which is what matters when 400 evaluations run back to back.
+// Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
+// ----------------------------------------------------------------------------------------------
+template <int BW>
+__global__ __launch_bounds__(64) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
+                                                   const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                                   const float4* res, float4* out, int CQI, int COUT, int relu_res) {
+    constexpr int A = BW * BW;
+    const int lane = threadIdx.x;
+    const int kq = lane >> 4, ci = lane & 15;
+    const int ctile = blockIdx.x, ct = blockIdx.y, board = blockIdx.z;
+    const int cell = ctile * 16 + ci;
+    const int cy = cell / BW, cx = cell - cy * BW;
+    const float4* xb = in + static_cast<size_t>(board) * A * CQI;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ncqg = CQI >> 2;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
+        const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
+        const float4* xp = xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
+        const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
+#pragma unroll 8
+        for (int cqg = 0; cqg < ncqg; ++cqg) {
+            float4 x = xp[cqg * 4];
+            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 w = wp[static_cast<size_t>(cqg) * 4 * COUT];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
+        }
+    }
+    // D row = cout 4*kq + reg, col = cell ci
+    if (cell < A) {
+        const int cqo = ct * 4 + kq;
+        const float4 sc = scale[cqo], sh = shift[cqo];
+        const size_t o = (static_cast<size_t>(board) * A + cell) * (COUT >> 2) + cqo;
+        float4 v;
+        v.x = fmaf(acc[0], sc.x, sh.x); v.y = fmaf(acc[1], sc.y, sh.y);
+        v.z = fmaf(acc[2], sc.z, sh.z); v.w = fmaf(acc[3], sc.w, sh.w);
+        if (relu_res) {
+            const float4 rr = res[o];
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        out[o] = v;
+    }
+}
+
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
 // hbuf[board][3][A]: channel 0,1 = policy head, 2 = value head.
 __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in, const float* __restrict__ w3,
@@ -621,6 +676,8 @@ struct ao_net {
     // device parameters
     std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]; conv_w[0] packed for nchq32
     float* conv0_w16 = nullptr;                    // conv1 weights packed for nchq16
+    float* conv0_w1 = nullptr;                     // conv1 weights packed for nchq1 (per-board NHWC path)
+    int nchq1 = 0;                                 // input channel quads of the per-board path: multiple of 4
     float *head_w3 = nullptr, *head_sc3 = nullptr, *head_sh3 = nullptr;
     float *wp_t = nullptr, *bp = nullptr, *w1_t = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
     // workspace (sized in boards, padded to 32)
@@ -704,9 +761,10 @@ int net_check(const ao_net* n, int board, int inplanes, int device, std::string*
 // per 32 boards and layer) spread small batches over more CUs.
 void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
     int mode = n->mode;
-    if (mode == 0) mode = ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
+    if (mode == 0) mode = (boards <= 48) ? 3 : ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 1;
     if (mode == 2) { *group = 16; *nchq = n->nchq16; }
+    else if (mode == 3) { *group = 1; *nchq = n->nchq1; }
     else { *group = 32; *nchq = n->nchq32; }
 }
 
@@ -771,7 +829,7 @@ static int ensure_workspace(ao_net* n, int boards) {
     const size_t act = static_cast<size_t>(boards) * n->A * n->planes;
     if (net_alloc(n, &n->act_x, act) || net_alloc(n, &n->act_t, act) ||
         net_alloc(n, &n->hbuf, static_cast<size_t>(boards) * 3 * n->A) ||
-        net_alloc(n, &n->il_in, static_cast<size_t>(boards) * n->A * std::max(n->nchq16, n->nchq32) * 4) ||
+        net_alloc(n, &n->il_in, static_cast<size_t>(boards) * n->A * std::max(std::max(n->nchq16, n->nchq32), n->nchq1) * 4) ||
         net_alloc(n, &n->tmp_p, static_cast<size_t>(boards) * n->A) || net_alloc(n, &n->tmp_v, boards))
         return 1;
     n->ws_boards = boards;
@@ -787,7 +845,34 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     int group = 32, nchq = 0;
     net_plan(n, boards, &group, &nchq);
     const int groups = (boards + group - 1) / group;
-    if (group == 16) {
+    if (group == 1) {
+        // per-board NHWC path: one wave per (16 cells, 16 couts, board)
+        auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
+            const dim3 grid((n->A + 15) / 16, n->planes / 16, boards), block(64);
+            const float4* w4 = reinterpret_cast<const float4*>(layer == 0 ? n->conv0_w1 : n->conv_w[layer]);
+            const bool timed = n->timing && layer > 0;
+            const int idx = timed ? timer_begin(n, s) : 0;
+            switch (n->B) {
+#define AO_BW_CASE(W)                                                                                         \
+    case W:                                                                                                   \
+        hipLaunchKernelGGL((k_conv_cells<W>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4,      \
+                           reinterpret_cast<const float4*>(n->conv_sc[layer]),                               \
+                           reinterpret_cast<const float4*>(n->conv_sh[layer]),                               \
+                           reinterpret_cast<const float4*>(res), reinterpret_cast<float4*>(out), cqi,        \
+                           n->planes, res ? 1 : 0);                                                          \
+        break;
+                AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+                AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+            }
+            if (timed) timer_end(n, idx, s);
+        };
+        conv(0, in_il, n->nchq1, nullptr, n->act_x);
+        for (int i = 0; i < n->nb; ++i) {
+            conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
+            conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
+        }
+    } else if (group == 16) {
         static bool lds_attr_done[16] = {};
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
@@ -855,6 +940,7 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     n->device = device;
     n->nchq32 = (((inplanes + 3) / 4) + 1) & ~1;  // consumed in pairs (32x32x2 MFMA, two quads per step)
     n->nchq16 = (((inplanes + 3) / 4) + 7) & ~7;  // 16 channels per k-step, steps taken in pairs
+    n->nchq1 = (((inplanes + 3) / 4) + 3) & ~3;   // 16 channels per k-step
     n->CQ = planes / 4;
     *out = n;
     return 0;
@@ -871,7 +957,8 @@ void ao_net_destroy(ao_net* n) {
 }
 
 int ao_net_set_mode(ao_net* n, int mode) {
-    if (mode < 0 || mode > 2) return n->fail("mode must be 0 (auto), 1 (layer kernels) or 2 (group-resident trunk)");
+    if (mode < 0 || mode > 3)
+        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk) or 3 (per-board)");
     n->mode = mode;
     return 0;
 }
@@ -942,6 +1029,7 @@ int ao_net_finalize(ao_net* n) {
         const std::vector<float>* w;
         if (get_param(n, "conv1.weight", static_cast<size_t>(P) * n->C * 9, &w)) return 1;
         if (upload(n, &n->conv0_w16, pack_conv(*w, P, n->C, n->nchq16))) return 1;
+        if (upload(n, &n->conv0_w1, pack_conv(*w, P, n->C, n->nchq1))) return 1;
     }
     for (int i = 0; i < n->nb; ++i) {
         const std::string pre = "layers." + std::to_string(i);
@@ -1030,7 +1118,10 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
     const double conv1 = 2.0 * n->A * 9.0 * n->C * n->planes * padded;
     std::string nm;
     double f;
-    if (group == 16) {
+    if (group == 1) {
+        nm = "k_conv_cells<" + std::to_string(n->B) + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
+        f = conv;
+    } else if (group == 16) {
         nm = "k_trunk16<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
              " 3x3 convs, one launch, fp32 MFMA 16x16x4)";
         f = conv1 + 2.0 * n->nb * conv;

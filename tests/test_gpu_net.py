@@ -18,7 +18,7 @@ def _native(nb, C, planes, B, seed):
     return net
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_golden_gv7_forward(mode):
     """mode 1: one kernel per conv (groups of 32 boards); mode 2: group-resident trunk (16)."""
     import torch
@@ -37,7 +37,7 @@ def test_golden_gv7_forward(mode):
         net.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("nb,B,planes,batch", [(4, 9, 128, 70), (10, 9, 128, 33), (2, 15, 128, 40),
                                                (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64)])
 def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
@@ -62,7 +62,7 @@ def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
     net.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_fused_search_matches_stepwise_and_oracle(oracle, mode):
     """ao_search (select -> native PVNet -> expand on one stream) == the stepwise protocol fed by
     the same network through ao_net_forward, and == the oracle replaying those (p, v)."""
