@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
 // workgroups of ~130 us, which is what matters when 400 evaluations run back to back.
 // Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
 // ----------------------------------------------------------------------------------------------
-template <int BW>
-__global__ __launch_bounds__(64) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
+template <int BW, int NCQG>  // NCQG = 16-channel k-steps per tap (compile-time: the loads can be hoisted)
+__global__ __launch_bounds__(64, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                    const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                    const float4* res, float4* out, int CQI, int COUT, int relu_res) {
     constexpr int A = BW * BW;
@@ -512,25 +512,44 @@ __global__ __launch_bounds__(64) void k_conv_cells(const float4* __restrict__ in
     const int cell = ctile * 16 + ci;
     const int cy = cell / BW, cx = cell - cy * BW;
     const float4* xb = in + static_cast<size_t>(board) * A * CQI;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int ncqg = CQI >> 2;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // Four independent accumulator chains (a single chain pays the 40-cycle dependent-MFMA latency
+    // on every instruction). The wave is alone on its SIMD, so memory latency is hidden only by
+    // loads in flight: a 4-deep ring of tap buffers keeps three taps (48 dwordx4 loads) ahead.
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    float4 rx[4][NCQG], rw[4][NCQG];
+    auto load_tap = [&](int tap, float4 (&X)[NCQG], float4 (&W)[NCQG]) {
         const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
         const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
         const float4* xp = xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
         const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
-#pragma unroll 8
-        for (int cqg = 0; cqg < ncqg; ++cqg) {
+#pragma unroll
+        for (int cqg = 0; cqg < NCQG; ++cqg) {
             float4 x = xp[cqg * 4];
             if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 w = wp[static_cast<size_t>(cqg) * 4 * COUT];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
+            X[cqg] = x;
+            W[cqg] = wp[static_cast<size_t>(cqg) * 4 * COUT];
         }
+    };
+    auto compute_tap = [&](const float4 (&X)[NCQG], const float4 (&W)[NCQG]) {
+#pragma unroll
+        for (int cqg = 0; cqg < NCQG; ++cqg) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].x, X[cqg].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].y, X[cqg].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].z, X[cqg].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].w, X[cqg].w, acc3, 0, 0, 0);
+        }
+    };
+    load_tap(0, rx[0], rw[0]);
+    load_tap(1, rx[1], rw[1]);
+    load_tap(2, rx[2], rw[2]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 3 < 9) load_tap(tap + 3, rx[(tap + 3) & 3], rw[(tap + 3) & 3]);
+        compute_tap(rx[tap & 3], rw[tap & 3]);
     }
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
     // D row = cout 4*kq + reg, col = cell ci
     if (cell < A) {
         const int cqo = ct * 4 + kq;
@@ -637,6 +656,78 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
     for (int o = threadIdx.x; o < planes; o += blockDim.x) part = fmaf(w2[o], s_hid[o], part);
     part = block_reduce(part, s_red, false);
     if (threadIdx.x == 0) value[board] = tanhf(part + b2[0]);
+}
+
+// Both heads of ONE board in one block (per-board NHWC input), for the small-batch path: all 256
+// threads share every reduction instead of 81 threads walking 162-long dot products.
+__global__ __launch_bounds__(256) void k_heads_board(const float4* __restrict__ act, const float* __restrict__ w3,
+                                                     const float* __restrict__ sc3, const float* __restrict__ sh3,
+                                                     const float* __restrict__ wp_t, const float* __restrict__ bp,
+                                                     const float* __restrict__ w1_t, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ policy, float* __restrict__ value, int A,
+                                                     int planes) {
+    extern __shared__ float s_hb[];  // [3*planes] w3 | [3A] h | [4][A] partial logits | [planes] hidden | [8]
+    float* s_w3 = s_hb;
+    float* s_h = s_w3 + 3 * planes;
+    float* s_part = s_h + 3 * A;
+    float* s_hid = s_part + 4 * A;
+    float* s_red = s_hid + planes;
+    const int tid = threadIdx.x;
+    const size_t board = blockIdx.x;
+    const int CQ = planes >> 2;
+    for (int i = tid; i < 3 * planes; i += 256) s_w3[i] = w3[i];
+    __syncthreads();
+    // 1x1 convs: one (cell, output channel) pair per thread
+    for (int i = tid; i < 3 * A; i += 256) {
+        const int c = i / A, cell = i - c * A;
+        const float4* xp = act + (board * A + cell) * CQ;
+        const float* w = s_w3 + c * planes;
+        float a0 = 0.f, a1 = 0.f;
+        for (int cq = 0; cq < CQ; cq += 2) {
+            const float4 x = xp[cq], y = xp[cq + 1];
+            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
+            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
+            a1 = fmaf(y.x, w[4 * cq + 4], a1); a1 = fmaf(y.y, w[4 * cq + 5], a1);
+            a1 = fmaf(y.z, w[4 * cq + 6], a1); a1 = fmaf(y.w, w[4 * cq + 7], a1);
+        }
+        s_h[i] = fmaxf(fmaf(a0 + a1, sc3[c], sh3[c]), 0.f);
+    }
+    __syncthreads();
+    // policy_fc: output a, the 2A-long dot product split in 4 slices
+    for (int i = tid; i < 4 * A; i += 256) {
+        const int part = i / A, a = i - part * A;
+        const int j0 = part * ((2 * A + 3) / 4), j1 = min(2 * A, j0 + (2 * A + 3) / 4);
+        float acc = 0.f;
+        for (int j = j0; j < j1; ++j) acc = fmaf(wp_t[static_cast<size_t>(j) * A + a], s_h[j], acc);
+        s_part[i] = acc;
+    }
+    // value_fc1 + ReLU
+    for (int o = tid; o < planes; o += 256) {
+        float acc = b1[o];
+        for (int j = 0; j < A; ++j) acc = fmaf(w1_t[static_cast<size_t>(j) * planes + o], s_h[2 * A + j], acc);
+        s_hid[o] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    float lmax = -3.0e38f;
+    for (int a = tid; a < A; a += 256) {
+        const float l = bp[a] + ((s_part[a] + s_part[A + a]) + (s_part[2 * A + a] + s_part[3 * A + a]));
+        s_part[a] = l;
+        lmax = fmaxf(lmax, l);
+    }
+    lmax = block_reduce(lmax, s_red, true);
+    float lsum = 0.f;
+    for (int a = tid; a < A; a += 256) {
+        const float ex = expf(s_part[a] - lmax);
+        s_part[a] = ex;
+        lsum += ex;
+    }
+    lsum = block_reduce(lsum, s_red, false);
+    for (int a = tid; a < A; a += 256) policy[board * A + a] = s_part[a] / lsum;
+    float part = 0.f;
+    for (int o = tid; o < planes; o += 256) part = fmaf(w2[o], s_hid[o], part);
+    part = block_reduce(part, s_red, false);
+    if (tid == 0) value[board] = tanhf(part + b2[0]);
 }
 
 // [batch][C][A] float32 (Agent.model's input layout, agents.py:175) -> interleaved batch
@@ -853,17 +944,25 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             const bool timed = n->timing && layer > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
             switch (n->B) {
+#define AO_CELLS_LAUNCH(W, Q)                                                                                 \
+    hipLaunchKernelGGL((k_conv_cells<W, Q>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4,      \
+                       reinterpret_cast<const float4*>(n->conv_sc[layer]),                                   \
+                       reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res), \
+                       reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0)
 #define AO_BW_CASE(W)                                                                                         \
     case W:                                                                                                   \
-        hipLaunchKernelGGL((k_conv_cells<W>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4,      \
-                           reinterpret_cast<const float4*>(n->conv_sc[layer]),                               \
-                           reinterpret_cast<const float4*>(n->conv_sh[layer]),                               \
-                           reinterpret_cast<const float4*>(res), reinterpret_cast<float4*>(out), cqi,        \
-                           n->planes, res ? 1 : 0);                                                          \
+        switch (cqi >> 2) {                                                                                   \
+            case 1: AO_CELLS_LAUNCH(W, 1); break;                                                             \
+            case 2: AO_CELLS_LAUNCH(W, 2); break;                                                             \
+            case 4: AO_CELLS_LAUNCH(W, 4); break;                                                             \
+            case 6: AO_CELLS_LAUNCH(W, 6); break;                                                             \
+            default: AO_CELLS_LAUNCH(W, 8); break;                                                            \
+        }                                                                                                     \
         break;
                 AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
                 AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
+#undef AO_CELLS_LAUNCH
             }
             if (timed) timer_end(n, idx, s);
         };
@@ -872,6 +971,12 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
             conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
         }
+        const size_t lds1 = (static_cast<size_t>(4) * n->planes + 7 * n->A + 8) * sizeof(float);
+        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(256), lds1, s, reinterpret_cast<const float4*>(n->act_x),
+                           n->head_w3, n->head_sc3, n->head_sh3, n->wp_t, n->bp, n->w1_t, n->b1, n->w2, n->b2, policy,
+                           value, n->A, n->planes);
+        NET_HIP(n, hipGetLastError());
+        return 0;
     } else if (group == 16) {
         static bool lds_attr_done[16] = {};
         switch (n->B) {
