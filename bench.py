@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--planes", type=int, default=128)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-game", action="store_true")
     ap.add_argument("--trunk-mode", type=int, default=0, help="0 auto, 1 layer kernels, 2 group-resident trunk")
     args = ap.parse_args()
 
@@ -247,6 +248,28 @@ def main():
                 "conv_time_share": (conv_ms * 1e-3) / dt if dt > 0 else None,
             },
         }
+        if world == 1 and G > 1 and not args.no_single_game:
+            # BASELINE configs[1] beside the headline: ONE game, 400 sims/move, same network
+            # (latency path: per-board conv kernels, no concurrency to hide behind)
+            try:
+                one = Engine(B, S, 5, games=1, noise=True, device=local)
+                one.seed(0, 0)
+                tau1 = np.ones(1, np.int8)
+                one.search(net, tau=tau1)
+                one.play()
+                one.sync()
+                t1 = time.perf_counter()
+                nmv = 6
+                for _ in range(nmv):
+                    one.search(net, tau=tau1)
+                    one.play()
+                one.sync()
+                d1 = time.perf_counter() - t1
+                out["single_game"] = {"workload": "BASELINE configs[1]: 1 game, %d sims/move, same net" % S,
+                                      "value": nmv / d1, "unit": "move-decisions/s", "ms_per_move": d1 / nmv * 1e3}
+                one.close()
+            except Exception as e:
+                out["single_game"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, S, args.blocks, args.planes, sd, args.cpu_budget)
