@@ -202,7 +202,7 @@ def main():
         # be collected inside this process); use the committed summary when it is for this workload
         traffic = None
         try:
-            with open(os.path.join(REPO, "profiles", "r1b_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r1d_traffic.json")) as f:
                 tj = json.load(f)
             if (tj["kernel"].split("<")[0] == kname.split("<")[0] and G == 4096 and B == 9
                     and args.blocks == 4 and args.planes == 128):
@@ -241,7 +241,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1b_pmc.txt)",
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1d_pmc.txt)",
                 "flop_per_launch": f_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": conv_launches,
