@@ -501,22 +501,36 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
 // workgroups of ~130 us, which is what matters when 400 evaluations run back to back.
 // Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
 // ----------------------------------------------------------------------------------------------
-template <int BW, int NCQG>  // NCQG = 16-channel k-steps per tap (compile-time: the loads can be hoisted)
-__global__ __launch_bounds__(64, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
+// NCQG = 16-channel k-steps per tap; NW = waves per tile (9: one tap each, 3: one tap row each)
+template <int BW, int NCQG, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                    const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                    const float4* res, float4* out, int CQI, int COUT, int relu_res) {
     constexpr int A = BW * BW;
-    const int lane = threadIdx.x;
+    // NW waves per tile, each takes 9/NW taps (that share of the K loop); the partial tiles are
+    // summed through LDS. A single wave per tile is bound by its own in-order chain of 144 loads;
+    // nine waves cut that chain to 16 (best for one board), three to 48 (best for a few dozen).
+    constexpr int TP = 9 / NW;
+    __shared__ float s_red[NW - 1][64][4];
+    const int lane = threadIdx.x & 63;
+    const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     const int kq = lane >> 4, ci = lane & 15;
-    const int ctile = blockIdx.x, ct = blockIdx.y, board = blockIdx.z;
+    // 1-D grid with the output-channel tile fastest: workgroups are dispatched round-robin over
+    // the 8 XCDs, so (for 8 tiles) XCD x only ever reads the weights of tile x -- 1/8 of the
+    // network per L2, which then stays resident from one evaluation to the next (the whole net
+    // is 5 MB, an XCD's L2 4 MB).
+    const int ntile = COUT >> 4;
+    const int ct = blockIdx.x % ntile;
+    const int rest = blockIdx.x / ntile;
+    constexpr int NCT = (BW * BW + 15) / 16;
+    const int ctile = rest % NCT, board = rest / NCT;
     const int cell = ctile * 16 + ci;
     const int cy = cell / BW, cx = cell - cy * BW;
     const float4* xb = in + static_cast<size_t>(board) * A * CQI;
-    // Four independent accumulator chains (a single chain pays the 40-cycle dependent-MFMA latency
-    // on every instruction). The wave is alone on its SIMD, so memory latency is hidden only by
-    // loads in flight: a 4-deep ring of tap buffers keeps three taps (48 dwordx4 loads) ahead.
+    // four independent accumulator chains (one chain would pay the 40-cycle dependent-MFMA latency
+    // on every instruction)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    float4 rx[4][NCQG], rw[4][NCQG];
+    float4 rx[TP][NCQG], rw[TP][NCQG];
     auto load_tap = [&](int tap, float4 (&X)[NCQG], float4 (&W)[NCQG]) {
         const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
         const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
@@ -539,20 +553,26 @@ __global__ __launch_bounds__(64, 1) void k_conv_cells(const float4* __restrict__
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].w, X[cqg].w, acc3, 0, 0, 0);
         }
     };
-    // (Pinning this order with sched_barrier -- 256 VGPRs, 48 loads in flight -- measured slower,
-    // 20 vs 17.6 us per layer at one board: the kernel is bound by the weight stream, which at
-    // 5 MB per network does not stay in one XCD's 4 MB L2 between evaluations.)
-    load_tap(0, rx[0], rw[0]);
-    load_tap(1, rx[1], rw[1]);
-    load_tap(2, rx[2], rw[2]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 3 < 9) load_tap(tap + 3, rx[(tap + 3) & 3], rw[(tap + 3) & 3]);
-        compute_tap(rx[tap & 3], rw[tap & 3]);
-    }
+    for (int j = 0; j < TP; ++j) load_tap(TP * w3 + j, rx[j], rw[j]);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+    if (w3 > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[w3 - 1][lane][r] = acc[r];
+    }
+    __syncthreads();
+    if (w3 > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = acc[r];
+#pragma unroll
+        for (int k = 0; k < NW - 1; ++k) t += s_red[k][lane][r];
+        acc[r] = t;
+    }
     // D row = cout 4*kq + reg, col = cell ci
     if (cell < A) {
         const int cqo = ct * 4 + kq;
@@ -855,7 +875,9 @@ int net_check(const ao_net* n, int board, int inplanes, int device, std::string*
 // per 32 boards and layer) spread small batches over more CUs.
 void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
     int mode = n->mode;
-    if (mode == 0) mode = (boards <= 48) ? 3 : ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
+    // measured crossovers on MI355X (9x9, 4 blocks): per-board path wins up to ~350 boards, the
+    // group-resident trunk needs ~3/4 of the CUs (one workgroup per 16 boards)
+    if (mode == 0) mode = (boards <= 320) ? 3 : ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 1;
     if (mode == 2) { *group = 16; *nchq = n->nchq16; }
     else if (mode == 3) { *group = 1; *nchq = n->nchq1; }
@@ -942,16 +964,22 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
         auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
-            const dim3 grid((n->A + 15) / 16, n->planes / 16, boards), block(64);
+            const int nw = (boards <= 4) ? 9 : 3;
+            const dim3 grid(((n->A + 15) / 16) * (n->planes / 16) * boards), block(64 * nw);
             const float4* w4 = reinterpret_cast<const float4*>(layer == 0 ? n->conv0_w1 : n->conv_w[layer]);
             const bool timed = n->timing && layer > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
             switch (n->B) {
-#define AO_CELLS_LAUNCH(W, Q)                                                                                 \
-    hipLaunchKernelGGL((k_conv_cells<W, Q>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4,      \
+#define AO_CELLS_LAUNCH2(W, Q, NWV)                                                                           \
+    hipLaunchKernelGGL((k_conv_cells<W, Q, NWV>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4, \
                        reinterpret_cast<const float4*>(n->conv_sc[layer]),                                   \
                        reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res), \
                        reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0)
+#define AO_CELLS_LAUNCH(W, Q)                                                                                 \
+    do {                                                                                                      \
+        if (nw == 9) AO_CELLS_LAUNCH2(W, Q, 9);                                                               \
+        else AO_CELLS_LAUNCH2(W, Q, 3);                                                                       \
+    } while (0)
 #define AO_BW_CASE(W)                                                                                         \
     case W:                                                                                                   \
         switch (cqi >> 2) {                                                                                   \
@@ -966,6 +994,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                 AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
 #undef AO_CELLS_LAUNCH
+#undef AO_CELLS_LAUNCH2
             }
             if (timed) timer_end(n, idx, s);
         };
