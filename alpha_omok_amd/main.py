@@ -145,14 +145,16 @@ def self_play(n_selfplay, seeds=None):
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
         act, win = eng.play()                             # utils.get_action + env.step
         refill = np.zeros(G, np.uint8)
+        waiting = len(queue)                              # episodes still without a slot
         for g in np.nonzero(active)[0]:
             ep = int(slot_ep[g])
             pis[ep].append(pi[g].copy())
             moves[ep].append(int(act[g]))
             if win[g] != 0:
                 wins[ep] = int(win[g])
-                if queue:
+                if waiting > 0:
                     refill[g] = 1
+                    waiting -= 1
                 else:
                     active[g] = 0
                     slot_ep[g] = -1
