@@ -234,3 +234,47 @@ def reset_iter(result_, cur_memory_):
     result_['Draw'] = 0
     total_epoch = 0
     cur_memory_.clear()
+
+
+# ---- checkpoint wire format (main.py:339-365): torch.save(state_dict) / pickled rep_memory, with the
+# iteration and step encoded in the file name and parsed back on load ----
+def save_model(agent, n_iter, step_, directory='data', datetime_now=None):
+    import os
+    from datetime import datetime
+    import torch
+    datetime_now = datetime_now or datetime.now().strftime('%y%m%d')
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, '{}_{}_{}_step_model.pickle'.format(datetime_now, n_iter, step_))
+    torch.save(agent.model.state_dict(), path)
+    return path
+
+
+def save_dataset(memory, n_iter, step_, directory='data', datetime_now=None):
+    import os
+    import pickle
+    from datetime import datetime
+    datetime_now = datetime_now or datetime.now().strftime('%y%m%d')
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, '{}_{}_{}_step_dataset.pickle'.format(datetime_now, n_iter, step_))
+    with open(path, 'wb') as f:
+        pickle.dump(memory, f, pickle.HIGHEST_PROTOCOL)
+    return path
+
+
+def load_data(model_path, dataset_path):
+    """Tolerant load like the reference: state.update(torch.load(path)); iteration / step come from
+    the file NAME ({yymmdd}_{iter}_{step}_step_model.pickle)."""
+    global rep_memory, step, start_iter
+    import os
+    import pickle
+    import torch
+    if model_path:
+        state = Agent.model.state_dict()
+        state.update(torch.load(model_path, map_location=device))
+        Agent.model.load_state_dict(state)
+        name = os.path.basename(model_path)
+        step = int(name.split('_')[2])
+        start_iter = int(name.split('_')[1]) + 1
+    if dataset_path:
+        with open(dataset_path, 'rb') as f:
+            rep_memory = deque(pickle.load(f), maxlen=MEMORY_SIZE)

@@ -175,3 +175,33 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     full = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
     assert r0["n"] == full.numel()
     assert (r0["grad"] - full).abs().max().item() < 1e-5
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """save_model / save_dataset / load_data (main.py:339-365): file naming carries iter and step;
+    the model file is a plain state_dict with the reference's keys."""
+    import torch
+    import alpha_omok_amd.main as main
+    from alpha_omok_amd.pvnet import PVNet
+
+    class A:
+        pass
+
+    main.Agent = A()
+    main.Agent.model = PVNet(1, 5, 32, 9)
+    main.device = torch.device("cpu")
+    main.rep_memory.clear()
+    main.rep_memory.extend([(np.zeros((5, 9, 9)), np.ones(81) / 81, 1.0)] * 3)
+    mp = main.save_model(main.Agent, 200, 1234, directory=str(tmp_path), datetime_now="180927")
+    dp = main.save_dataset(main.rep_memory, 200, 1234, directory=str(tmp_path), datetime_now="180927")
+    assert os.path.basename(mp) == "180927_200_1234_step_model.pickle"
+    sd = torch.load(mp)
+    assert set(sd.keys()) == set(pvnet_weights.make_state_dict(1, 5, 32, 9, 0).keys())
+    fresh = PVNet(1, 5, 32, 9)
+    main.Agent.model = fresh
+    main.rep_memory.clear()
+    main.load_data(mp, dp)
+    assert main.step == 1234 and main.start_iter == 201
+    assert len(main.rep_memory) == 3 and main.rep_memory.maxlen == main.MEMORY_SIZE
+    for k, v in sd.items():
+        assert torch.equal(fresh.state_dict()[k], v)
