@@ -120,3 +120,41 @@ def test_fused_search_matches_stepwise_and_oracle(oracle, mode):
     e1.close()
     e2.close()
     net.close()
+
+
+def test_full_size_batch_all_paths_agree():
+    """4096 boards (one workgroup per CU in the group-resident trunk): the three trunk paths are
+    independent implementations and must agree; a sample is checked against the torch fp32 net.
+    Repeated a few times: a stale-cache or race bug in the in-kernel layer hand-off would show up
+    as run-to-run differences under full load."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    nb, B, planes, batch = 4, 9, 128, 4096
+    sd = pvnet_weights.make_state_dict(nb, 5, planes, B, 321)
+    ref = PVNet(nb, 5, planes, B)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ref.eval()
+    rs = np.random.RandomState(1)
+    x = (rs.rand(batch, 5, B, B) < 0.25).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    net = ref.to_native(0)
+    outs = {}
+    for mode in (2, 1, 3, 2, 2):
+        net.set_mode(mode)
+        p, v = net(xt)
+        torch.cuda.synchronize()
+        p, v = p.cpu().numpy(), v.cpu().numpy()
+        assert np.isfinite(p).all() and np.isfinite(v).all()
+        if mode in outs:
+            np.testing.assert_array_equal(outs[mode][0], p)      # same path twice: bit-identical
+            np.testing.assert_array_equal(outs[mode][1], v)
+        outs[mode] = (p, v)
+    for m in (1, 3):
+        assert np.abs(outs[2][0] - outs[m][0]).max() < 2e-5, m
+        assert np.abs(outs[2][1] - outs[m][1]).max() < 2e-5, m
+    idx = rs.choice(batch, 96, replace=False)
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x[idx]))
+    assert np.abs(outs[2][0][idx] - rp.numpy()).max() < TOL
+    assert np.abs(outs[2][1][idx] - rv.numpy()).max() < TOL
+    net.close()
