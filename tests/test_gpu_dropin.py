@@ -138,3 +138,34 @@ def test_self_play_concurrent_episodes_match_oracle_games(oracle):
     assert off == len(cm)
     assert [main.result[k] for k in ("Black", "White", "Draw")] == [res[1], res[2], res[3]]
     assert len(main.rep_memory) == min(8 * len(cm), main.MEMORY_SIZE)
+
+
+def test_head_to_head_two_agents_match_oracle(oracle):
+    """eval_main's call pattern: two ZeroAgents (noise off, tau 0) alternate on one game, each
+    re-rooting two plies down after the opponent's reply -- against two oracle agents fed the same way."""
+    from alpha_omok_amd import agents, evaluate, utils
+    agents.PRINT_MCTS = False
+    B, S = 9, 36
+    pa, pb = agents.ZeroAgent(B, S, 5, noise=False), agents.ZeroAgent(B, S, 5, noise=False)
+    pa.model, pb.model = StubModel(oracle, 1), StubModel(oracle, 0)
+    oa = oracle.Agent(B, S, 5, noise=False, evaluator="stub1")
+    ob = oracle.Agent(B, S, 5, noise=False, evaluator="stub0")
+    np.random.seed(11)
+    win, moves = evaluate.play_match(pa, pb, B, enemy_turn=1, max_plies=30)
+    # oracle replay of the same protocol on one shared stream (both oracle agents share one Rng
+    # the way the reference's players share np.random)
+    shared = oracle.Rng(11)
+    root = (0,)
+    for t, mv in enumerate(moves):
+        ag = ob if t % 2 == 1 else oa
+        ag.rng.set_state(shared.state_words(), shared.pos)
+        pi, vis, pol = ag.get_pi(root, 0)
+        shared.set_state(ag.rng.state_words(), ag.rng.pos)
+        k = int((pi == pi.max()).sum())
+        a = int(np.flatnonzero(pi == pi.max())[shared.choice(k)])
+        assert a == mv, "ply %d" % t
+        root = root + (a,)
+    assert np.random.get_state()[2] == shared.pos
+    assert win == oracle.check_win(oracle.get_board(list(root)[1:], B), 5)
+    pe, ee = evaluate.elo(1500.0, 1500.0, 1.0, 0.0)
+    assert abs(pe - 1516.0) < 1e-9 and abs(ee - 1484.0) < 1e-9
