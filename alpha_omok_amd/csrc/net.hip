@@ -230,7 +230,9 @@ template <int BW, int XT, int TPW>
 __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
                                             const float4* __restrict__ wt, const float4* __restrict__ scp,
                                             const float4* __restrict__ shp, const bool RES, int cqi, int cq_real,
-                                            int COUT, size_t gbase, int ct0, int kq, int b) {
+                                            int COUT, size_t gbase, int ct0, int kq, int b, int yb, int ye) {
+    // computes the output rows [yb, ye) of the layer (the whole board inside the resident kernel, a
+    // row chunk when one launch per layer spreads a group over several workgroups)
     constexpr int NXT = (BW + XT - 1) / XT;
     constexpr int NX = XT + 2;
     constexpr int GB = 16;
@@ -309,13 +311,13 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
             // sched_barrier keeps each weight re-load BELOW the last MFMA that reads the registers it
             // overwrites; hoisted above, it would need a second copy of the weight fragments
             load_x(nyi, ncq, Xn);
-            if (live && yi + 1 < BW) taps(X, 0, acc2);  // dy = 0 -> output row yi + 1
+            if (live && yi + 1 < ye) taps(X, 0, acc2);            // dy = 0 -> output row yi + 1
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 0);
-            if (live) taps(X, 1, acc1);                 // dy = 1 -> output row yi
+            if (live && yi >= yb && yi < ye) taps(X, 1, acc1);    // dy = 1 -> output row yi
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 1);
-            if (live && yi >= 1) taps(X, 2, acc0);      // dy = 2 -> output row yi - 1
+            if (live && yi - 1 >= yb) taps(X, 2, acc0);           // dy = 2 -> output row yi - 1
             __builtin_amdgcn_sched_barrier(0);
             load_w(ncq, 2);
         };
@@ -363,22 +365,25 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
                 }
         };
 
-        load_x(0, 0, xa);
+        // input rows that feed the output rows [yb, ye): one halo row above and below
+        const int y0 = yb > 0 ? yb - 1 : 0;
+        const int y1 = ye < BW ? ye : BW - 1;
+        load_x(y0, 0, xa);
         load_w(0, 0);
         load_w(0, 1);
         load_w(0, 2);
-        for (int yi = 0; yi < BW; ++yi) {
+        for (int yi = y0; yi <= y1; ++yi) {
             for (int cqg = 0; cqg < ncqg; cqg += 2) {
                 step(xa, xb, yi, yi, cqg + 1, cqg * 4 < cq_real);
                 const bool same = cqg + 2 < ncqg;
-                const bool last = !same && (yi + 1 >= BW);  // end of the layer: harmless re-load
+                const bool last = !same && (yi + 1 > y1);  // end of the chunk: harmless re-load
                 step(xb, xa, yi, same || last ? yi : yi + 1, same ? cqg + 2 : (last ? cqg + 1 : 0),
                      (cqg + 1) * 4 < cq_real);
             }
-            if (yi >= 1) epilogue(yi - 1);
+            if (yi - 1 >= yb) epilogue(yi - 1);
             slide();
         }
-        epilogue(BW - 1);  // after the last slide the bottom row sits in acc0
+        if (ye == BW) epilogue(BW - 1);  // after the last slide the bottom row sits in acc0
     }
 }
 
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
         float4* dst = (l == 0) ? a.bufA : ((l & 1) ? a.bufB : a.bufA);
         // even l > 0: second conv of a ResBlock, + x (held in bufA = dst)
         trunk_layer<BW, XT, TPW>(src, dst, a.layers[l].w, a.layers[l].sc, a.layers[l].sh, l > 0 && (l & 1) == 0,
-                                 l == 0 ? a.cq0 : a.CQ, l == 0 ? a.cq0_real : a.CQ, a.COUT, gbase, ct0, kq, b);
+                                 l == 0 ? a.cq0 : a.CQ, l == 0 ? a.cq0_real : a.CQ, a.COUT, gbase, ct0, kq, b, 0, BW);
         // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
         // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -588,6 +593,31 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         out[o] = v;
     }
+}
+
+// One conv layer per launch for medium batches: a 16-board group is split into `nch` row chunks,
+// one workgroup each, so 64 groups x 4 chunks still give every CU one workgroup. The chunk runs
+// the same sliding-window code over its rows (plus one halo input row on each side); the launch
+// boundary is the synchronisation between layers, nothing is exchanged inside a launch.
+struct LayerArgs {
+    const float4* src;
+    float4* dst;
+    TrunkLayer layer;
+    int res, cqi, cq_real, COUT, nch;
+};
+
+template <int BW, int XT>
+__global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
+    constexpr int A = BW * BW;
+    const int grp = blockIdx.x / a.nch;
+    const int c = blockIdx.x - grp * a.nch;
+    const int base = BW / a.nch, extra = BW % a.nch;
+    const int yb = c * base + (c < extra ? c : extra);
+    const int ye = yb + base + (c < extra ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    trunk_layer<BW, XT, 1>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real, a.COUT,
+                           static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
 }
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
@@ -782,7 +812,8 @@ struct ao_net {
     int nchq32 = 0;  // input channel quads of the layer-kernel path (groups of 32 boards)
     int nchq16 = 0;  // ... of the group-resident path (groups of 16 boards): multiple of 8
     int CQ = 0;
-    int mode = 0;    // 0 auto, 1 layer kernels, 2 group-resident trunk
+    int mode = 0;    // 0 auto, 1 layer kernels (32), 2 group-resident trunk, 3 per-board, 4 row-chunked layers (16)
+    int num_cu = 256;
     bool finalized = false;
     std::string err;
     std::map<std::string, std::vector<float>> params;
@@ -870,16 +901,36 @@ int net_check(const ao_net* n, int board, int inplanes, int device, std::string*
 }
 
 // Execution plan for a batch of `boards` positions: which trunk runs and which interleaved input
-// layout (boards per group, channel quads) it expects. The group-resident trunk needs one
-// workgroup per 16 boards to fill the chip; below ~3/4 of the CUs the layer kernels (9 blocks
-// per 32 boards and layer) spread small batches over more CUs.
-void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
+// layout (boards per group, channel quads) it expects.
+//   3  per-board NHWC, cells as MFMA N      -- up to ~320 boards (latency path)
+//   2  group-resident trunk, 16 boards/WG   -- >= 192 groups: one workgroup per CU for the whole net
+//   4  one launch per layer over (16-board group x row chunk) -- everything in between
+//   1  one launch per layer over 32-board groups x board rows (first-generation kernel, explicit only)
+int pick_mode_public(const ao_net* n, int boards);
+static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     int mode = n->mode;
-    // measured crossovers on MI355X (9x9, 4 blocks): per-board path wins up to ~350 boards, the
-    // group-resident trunk needs ~3/4 of the CUs (one workgroup per 16 boards)
-    if (mode == 0) mode = (boards <= 320) ? 3 : ((boards + 15) / 16 >= 192 && n->planes == 128) ? 2 : 1;
-    if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 1;
-    if (mode == 2) { *group = 16; *nchq = n->nchq16; }
+    const int g16 = (boards + 15) / 16;
+    if (mode == 0) mode = (boards <= 320) ? 3 : (g16 >= 192 ? 2 : 4);
+    if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
+    int nch = 1;
+    if (mode == 4) {
+        // row chunks per group: minimise (rounds of workgroups over the CUs) x (rows per chunk)
+        long best = -1;
+        for (int c = 1; c <= n->B; ++c) {
+            const long rounds = (static_cast<long>(g16) * c + n->num_cu - 1) / n->num_cu;
+            const long cost = rounds * ((n->B + c - 1) / c);
+            if (best < 0 || cost < best) { best = cost; nch = c; }
+        }
+    }
+    if (nch_out) *nch_out = nch;
+    return mode;
+}
+
+int pick_mode_public(const ao_net* n, int boards) { return pick_mode(n, boards, nullptr); }
+
+void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
+    const int mode = pick_mode(n, boards, nullptr);
+    if (mode == 2 || mode == 4) { *group = 16; *nchq = n->nchq16; }
     else if (mode == 3) { *group = 1; *nchq = n->nchq1; }
     else { *group = 32; *nchq = n->nchq32; }
 }
@@ -958,8 +1009,9 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
-    int group = 32, nchq = 0;
+    int group = 32, nchq = 0, nch = 1;
     net_plan(n, boards, &group, &nchq);
+    const int mode = pick_mode(n, boards, &nch);
     const int groups = (boards + group - 1) / group;
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
@@ -1009,6 +1061,36 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                            value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
         return 0;
+    } else if (group == 16 && mode == 4) {
+        auto layer = [&](int l, const float* in, int cqi, int cq_real, bool res, float* out) {
+            LayerArgs a;
+            a.src = reinterpret_cast<const float4*>(in);
+            a.dst = reinterpret_cast<float4*>(out);
+            a.layer.w = reinterpret_cast<const float4*>(l == 0 ? n->conv0_w16 : n->conv_w[l]);
+            a.layer.sc = reinterpret_cast<const float4*>(n->conv_sc[l]);
+            a.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+            a.res = res ? 1 : 0; a.cqi = cqi; a.cq_real = cq_real; a.COUT = n->planes; a.nch = nch;
+            const dim3 grid(groups * nch), block(64 * (n->planes / 16));
+            const bool timed = n->timing && l > 0;
+            const int idx = timed ? timer_begin(n, s) : 0;
+            switch (n->B) {
+#define AO_BW_CASE(W)                                                                       \
+    case W: {                                                                               \
+        constexpr int XT_ = (W <= 9) ? W : 5;                                               \
+        hipLaunchKernelGGL((k_layer16<W, XT_>), grid, block, 0, s, a);                       \
+    } break;
+                AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+                AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+            }
+            if (timed) timer_end(n, idx, s);
+        };
+        layer(0, in_il, n->nchq16, (n->C + 3) / 4, false, n->act_x);
+        for (int i = 0; i < n->nb; ++i) {
+            layer(1 + 2 * i, n->act_x, n->CQ, n->CQ, false, n->act_t);
+            layer(2 + 2 * i, n->act_t, n->CQ, n->CQ, true, n->act_x);   // + x, in place
+        }
+        // heads below (k_head_conv / k_head_fc on the 16-board layout)
     } else if (group == 16) {
         static bool lds_attr_done[16] = {};
         switch (n->B) {
@@ -1079,6 +1161,11 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     n->nchq16 = (((inplanes + 3) / 4) + 7) & ~7;  // 16 channels per k-step, steps taken in pairs
     n->nchq1 = (((inplanes + 3) / 4) + 3) & ~3;   // 16 channels per k-step
     n->CQ = planes / 4;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            n->num_cu = prop.multiProcessorCount;
+    }
     *out = n;
     return 0;
 }
@@ -1094,8 +1181,8 @@ void ao_net_destroy(ao_net* n) {
 }
 
 int ao_net_set_mode(ao_net* n, int mode) {
-    if (mode < 0 || mode > 3)
-        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk) or 3 (per-board)");
+    if (mode < 0 || mode > 4)
+        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board) or 4 (row-chunked)");
     n->mode = mode;
     return 0;
 }
@@ -1257,6 +1344,9 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
     double f;
     if (group == 1) {
         nm = "k_conv_cells<" + std::to_string(n->B) + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
+        f = conv;
+ } else if (group == 16 && ao::pick_mode_public(n, boards) == 4) {
+        nm = "k_layer16<" + std::to_string(n->B) + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
     } else if (group == 16) {
         nm = "k_trunk16<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +

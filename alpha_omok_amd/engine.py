@@ -63,7 +63,7 @@ class Net:
         return pol, val
 
     def set_mode(self, mode):
-        """0 auto, 1 layer kernels (groups of 32), 2 group-resident trunk (groups of 16), 3 per-board."""
+        """0 auto, 1 layer kernels (32-board groups), 2 group-resident trunk, 3 per-board, 4 row-chunked layers."""
         self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
 
     def dominant_kernel(self, boards):

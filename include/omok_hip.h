@@ -138,7 +138,8 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
 /* Trunk execution: 0 = auto (by batch size), 1 = one kernel per 3x3 conv over groups of 32 boards
  * (medium batches), 2 = group-resident trunk: one workgroup carries 16 boards through every conv
  * layer in a single launch (4096 boards = 256 groups = one per CU), 3 = per-board NHWC with the
- * cells as the MFMA N dimension (latency path for a handful of games). All fp32. */
+ * cells as the MFMA N dimension (latency path for a handful of games), 4 = one launch per layer
+ * over (16-board group x row chunk) for the batch sizes in between. All fp32. */
 int  ao_net_set_mode(ao_net *n, int mode);
 /* total device time (ms) and launch count of the dominant trunk kernel since the last call
  * (HIP events on the launch stream); used by bench.py's roofline. */

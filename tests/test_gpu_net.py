@@ -18,7 +18,7 @@ def _native(nb, C, planes, B, seed):
     return net
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_golden_gv7_forward(mode):
     """mode 1: one kernel per conv (groups of 32 boards); mode 2: group-resident trunk (16)."""
     import torch
@@ -37,7 +37,7 @@ def test_golden_gv7_forward(mode):
         net.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("nb,B,planes,batch", [(4, 9, 128, 70), (10, 9, 128, 33), (2, 15, 128, 40),
                                                (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64)])
 def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
@@ -62,7 +62,7 @@ def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
     net.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_fused_search_matches_stepwise_and_oracle(oracle, mode):
     """ao_search (select -> native PVNet -> expand on one stream) == the stepwise protocol fed by
     the same network through ao_net_forward, and == the oracle replaying those (p, v)."""
@@ -139,7 +139,7 @@ def test_full_size_batch_all_paths_agree():
     xt = torch.from_numpy(x).cuda()
     net = ref.to_native(0)
     outs = {}
-    for mode in (2, 1, 3, 2, 2):
+    for mode in (2, 1, 3, 4, 2, 2):
         net.set_mode(mode)
         p, v = net(xt)
         torch.cuda.synchronize()
@@ -149,7 +149,7 @@ def test_full_size_batch_all_paths_agree():
             np.testing.assert_array_equal(outs[mode][0], p)      # same path twice: bit-identical
             np.testing.assert_array_equal(outs[mode][1], v)
         outs[mode] = (p, v)
-    for m in (1, 3):
+    for m in (1, 3, 4):
         assert np.abs(outs[2][0] - outs[m][0]).max() < 2e-5, m
         assert np.abs(outs[2][1] - outs[m][1]).max() < 2e-5, m
     idx = rs.choice(batch, 96, replace=False)
