@@ -349,8 +349,13 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
                     u32x4 o;
                     o.x = __float_as_uint(fmaxf(vx, 0.f)); o.y = __float_as_uint(fmaxf(vy, 0.f));
                     o.z = __float_as_uint(fmaxf(vz, 0.f)); o.w = __float_as_uint(fmaxf(vw, 0.f));
+                    // The whole address goes into the per-lane offset, soffset stays the constant 0:
+                    // a 128-bit MUBUF store reads its data registers for a few cycles after issue,
+                    // and the compiler only inserts the wait states that protects them from the
+                    // next VALU write when soffset is NOT an SGPR. With an SGPR soffset the rows
+                    // of boards 12-15 (the last data beat) were overwritten on gfx950.
                     if (xo < BW)
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, lane_x, orow + (xo * CQO + tl * 4) * GB * 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, lane_x + orow + (xo * CQO + tl * 4) * GB * 16, 0, 0);
                 }
             }
         };
