@@ -34,6 +34,7 @@
 
 #include "../../include/omok_hip.h"
 #include "engine_types.hpp"
+#include "net_device.hpp"
 
 namespace ao {
 
@@ -194,7 +195,6 @@ __global__ __launch_bounds__(256) void k_conv3x3(const float4* __restrict__ in,
 // act[grp][cell][cq][16][4]. Wave w owns output-channel tile w (16 couts) and walks the board row
 // by row with BW accumulators (4 VGPR each); 8 waves = 128 output channels, 2 waves per SIMD.
 // ----------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TrunkLayer {
     const float4* w;   // [9][cqi][COUT] float4
@@ -511,20 +511,13 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
 // workgroups of ~130 us, which is what matters when 400 evaluations run back to back.
 // Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
 // ----------------------------------------------------------------------------------------------
-// NCQG = 16-channel k-steps per tap; NW = waves per tile (9: one tap each, 3: one tap row each)
+// NCQG = 16-channel k-steps per tap; NW = waves per tile (9: one tap each, 3: one tap row each).
+// The tile code is conv_cells_tile (net_device.hpp), shared with the persistent single-game kernel.
 template <int BW, int NCQG, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                    const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                    const float4* res, float4* out, int CQI, int COUT, int relu_res) {
-    constexpr int A = BW * BW;
-    // NW waves per tile, each takes 9/NW taps (that share of the K loop); the partial tiles are
-    // summed through LDS. A single wave per tile is bound by its own in-order chain of 144 loads;
-    // nine waves cut that chain to 16 (best for one board), three to 48 (best for a few dozen).
-    constexpr int TP = 9 / NW;
-    __shared__ float s_red[NW - 1][64][4];
-    const int lane = threadIdx.x & 63;
-    const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-    const int kq = lane >> 4, ci = lane & 15;
+    __shared__ float s_red[(NW - 1) * 64 * 4];
     // 1-D grid with the output-channel tile fastest: workgroups are dispatched round-robin over
     // the 8 XCDs, so (for 8 tiles) XCD x only ever reads the weights of tile x -- 1/8 of the
     // network per L2, which then stays resident from one evaluation to the next (the whole net
@@ -533,71 +526,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
     const int ct = blockIdx.x % ntile;
     const int rest = blockIdx.x / ntile;
     constexpr int NCT = (BW * BW + 15) / 16;
-    const int ctile = rest % NCT, board = rest / NCT;
-    const int cell = ctile * 16 + ci;
-    const int cy = cell / BW, cx = cell - cy * BW;
-    const float4* xb = in + static_cast<size_t>(board) * A * CQI;
-    // four independent accumulator chains (one chain would pay the 40-cycle dependent-MFMA latency
-    // on every instruction)
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    float4 rx[TP][NCQG], rw[TP][NCQG];
-    auto load_tap = [&](int tap, float4 (&X)[NCQG], float4 (&W)[NCQG]) {
-        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
-        const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
-        const float4* xp = xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
-        const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
-#pragma unroll
-        for (int cqg = 0; cqg < NCQG; ++cqg) {
-            float4 x = xp[cqg * 4];
-            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            X[cqg] = x;
-            W[cqg] = wp[static_cast<size_t>(cqg) * 4 * COUT];
-        }
-    };
-    auto compute_tap = [&](const float4 (&X)[NCQG], const float4 (&W)[NCQG]) {
-#pragma unroll
-        for (int cqg = 0; cqg < NCQG; ++cqg) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].x, X[cqg].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].y, X[cqg].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].z, X[cqg].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].w, X[cqg].w, acc3, 0, 0, 0);
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < TP; ++j) load_tap(TP * w3 + j, rx[j], rw[j]);
-#pragma unroll
-    for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
-    f32x4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-    if (w3 > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_red[w3 - 1][lane][r] = acc[r];
-    }
-    __syncthreads();
-    if (w3 > 0) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float t = acc[r];
-#pragma unroll
-        for (int k = 0; k < NW - 1; ++k) t += s_red[k][lane][r];
-        acc[r] = t;
-    }
-    // D row = cout 4*kq + reg, col = cell ci
-    if (cell < A) {
-        const int cqo = ct * 4 + kq;
-        const float4 sc = scale[cqo], sh = shift[cqo];
-        const size_t o = (static_cast<size_t>(board) * A + cell) * (COUT >> 2) + cqo;
-        float4 v;
-        v.x = fmaf(acc[0], sc.x, sh.x); v.y = fmaf(acc[1], sc.y, sh.y);
-        v.z = fmaf(acc[2], sc.z, sh.z); v.w = fmaf(acc[3], sc.w, sh.w);
-        if (relu_res) {
-            const float4 rr = res[o];
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        out[o] = v;
-    }
+    conv_cells_tile<BW, NCQG, NW>(in, wt, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red);
 }
 
 // One conv layer per launch for medium batches: a 16-board group is split into `nch` row chunks,
@@ -658,21 +587,6 @@ __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in
     h[2 * A] = fmaxf(fmaf(a2, sc3[2], sh3[2]), 0.f);
 }
 
-__device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(v, o);
-        v = is_max ? fmaxf(v, t) : v + t;
-    }
-    __syncthreads();
-    if (lane == 0) s_red[wid] = v;
-    __syncthreads();
-    float r = s_red[0];
-    for (int i = 1; i < static_cast<int>(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, s_red[i]) : r + s_red[i];
-    return r;
-}
-
 // policy_fc + softmax (model.py:40-50), value_fc1 + ReLU + value_fc2 + tanh (model.py:59-73).
 // One block per board. The flatten order before the FCs is NCHW (c*A + cell), which is hbuf's.
 __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf, const float* __restrict__ wp_t,
@@ -716,76 +630,14 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
     if (threadIdx.x == 0) value[board] = tanhf(part + b2[0]);
 }
 
-// Both heads of ONE board in one block (per-board NHWC input), for the small-batch path: all 256
-// threads share every reduction instead of 81 threads walking 162-long dot products.
-__global__ __launch_bounds__(256) void k_heads_board(const float4* __restrict__ act, const float* __restrict__ w3,
-                                                     const float* __restrict__ sc3, const float* __restrict__ sh3,
-                                                     const float* __restrict__ wp_t, const float* __restrict__ bp,
-                                                     const float* __restrict__ w1_t, const float* __restrict__ b1,
-                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+// Both heads of ONE board in one block (per-board NHWC input), for the small-batch path
+// (heads_board_dev, net_device.hpp).
+__global__ __launch_bounds__(512) void k_heads_board(HeadParams h, const float4* __restrict__ act,
                                                      float* __restrict__ policy, float* __restrict__ value, int A,
                                                      int planes) {
-    extern __shared__ float s_hb[];  // [3*planes] w3 | [3A] h | [4][A] partial logits | [planes] hidden | [8]
-    float* s_w3 = s_hb;
-    float* s_h = s_w3 + 3 * planes;
-    float* s_part = s_h + 3 * A;
-    float* s_hid = s_part + 4 * A;
-    float* s_red = s_hid + planes;
-    const int tid = threadIdx.x;
+    extern __shared__ float s_hb[];
     const size_t board = blockIdx.x;
-    const int CQ = planes >> 2;
-    for (int i = tid; i < 3 * planes; i += 256) s_w3[i] = w3[i];
-    __syncthreads();
-    // 1x1 convs: one (cell, output channel) pair per thread
-    for (int i = tid; i < 3 * A; i += 256) {
-        const int c = i / A, cell = i - c * A;
-        const float4* xp = act + (board * A + cell) * CQ;
-        const float* w = s_w3 + c * planes;
-        float a0 = 0.f, a1 = 0.f;
-        for (int cq = 0; cq < CQ; cq += 2) {
-            const float4 x = xp[cq], y = xp[cq + 1];
-            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
-            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
-            a1 = fmaf(y.x, w[4 * cq + 4], a1); a1 = fmaf(y.y, w[4 * cq + 5], a1);
-            a1 = fmaf(y.z, w[4 * cq + 6], a1); a1 = fmaf(y.w, w[4 * cq + 7], a1);
-        }
-        s_h[i] = fmaxf(fmaf(a0 + a1, sc3[c], sh3[c]), 0.f);
-    }
-    __syncthreads();
-    // policy_fc: output a, the 2A-long dot product split in 4 slices
-    for (int i = tid; i < 4 * A; i += 256) {
-        const int part = i / A, a = i - part * A;
-        const int j0 = part * ((2 * A + 3) / 4), j1 = min(2 * A, j0 + (2 * A + 3) / 4);
-        float acc = 0.f;
-        for (int j = j0; j < j1; ++j) acc = fmaf(wp_t[static_cast<size_t>(j) * A + a], s_h[j], acc);
-        s_part[i] = acc;
-    }
-    // value_fc1 + ReLU
-    for (int o = tid; o < planes; o += 256) {
-        float acc = b1[o];
-        for (int j = 0; j < A; ++j) acc = fmaf(w1_t[static_cast<size_t>(j) * planes + o], s_h[2 * A + j], acc);
-        s_hid[o] = fmaxf(acc, 0.f);
-    }
-    __syncthreads();
-    float lmax = -3.0e38f;
-    for (int a = tid; a < A; a += 256) {
-        const float l = bp[a] + ((s_part[a] + s_part[A + a]) + (s_part[2 * A + a] + s_part[3 * A + a]));
-        s_part[a] = l;
-        lmax = fmaxf(lmax, l);
-    }
-    lmax = block_reduce(lmax, s_red, true);
-    float lsum = 0.f;
-    for (int a = tid; a < A; a += 256) {
-        const float ex = expf(s_part[a] - lmax);
-        s_part[a] = ex;
-        lsum += ex;
-    }
-    lsum = block_reduce(lsum, s_red, false);
-    for (int a = tid; a < A; a += 256) policy[board * A + a] = s_part[a] / lsum;
-    float part = 0.f;
-    for (int o = tid; o < planes; o += 256) part = fmaf(w2[o], s_hid[o], part);
-    part = block_reduce(part, s_red, false);
-    if (tid == 0) value[board] = tanhf(part + b2[0]);
+    heads_board_dev(h, act + board * A * (planes >> 2), policy + board * A, value + board, A, planes, s_hb);
 }
 
 // [batch][C][A] float32 (Agent.model's input layout, agents.py:175) -> interleaved batch
@@ -1008,6 +860,13 @@ static int ensure_workspace(ao_net* n, int boards) {
     return 0;
 }
 
+static HeadParams head_params(const ao_net* n) {
+    HeadParams h;
+    h.w3 = n->head_w3; h.sc3 = n->head_sc3; h.sh3 = n->head_sh3;
+    h.wp_t = n->wp_t; h.bp = n->bp; h.w1_t = n->w1_t; h.b1 = n->b1; h.w2 = n->w2; h.b2 = n->b2;
+    return h;
+}
+
 // in_il: interleaved batch in the layout net_plan(n, boards) announced. policy/value must have
 // room for `boards` rounded up to the plan's group size.
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s) {
@@ -1060,10 +919,9 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
             conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
         }
-        const size_t lds1 = (static_cast<size_t>(4) * n->planes + 7 * n->A + 8) * sizeof(float);
-        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(256), lds1, s, reinterpret_cast<const float4*>(n->act_x),
-                           n->head_w3, n->head_sc3, n->head_sh3, n->wp_t, n->bp, n->w1_t, n->b1, n->w2, n->b2, policy,
-                           value, n->A, n->planes);
+        const size_t lds1 = heads_lds_floats(n->A, n->planes) * sizeof(float);
+        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(512), lds1, s, head_params(n),
+                           reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
         return 0;
     } else if (group == 16 && mode == 4) {

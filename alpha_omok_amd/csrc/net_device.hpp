@@ -1,0 +1,242 @@
+// net_device.hpp -- device code of the small-batch ("latency") network path, shared by the
+// per-layer kernels of net.hip (k_conv_cells, k_heads_board) and by the persistent single-game
+// search kernel (fused_small.hip).
+//
+// Layout: per-board NHWC, act[board][cell][channel] as float4 channel quads. The CELLS of one
+// board are the MFMA N dimension:   D[cout 16][cell 16] += Wt[cout 16][k 4] * X[k 4][cell 16]
+// (model.py:6-31: bias-free 3x3 conv, BatchNorm folded to scale/shift, residual, ReLU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ao {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// parameters of both heads (model.py:34-73); BatchNorm folded into sc3/sh3
+struct HeadParams {
+    const float* w3;    // [3][planes]   1x1 convs: 2 policy channels + 1 value channel
+    const float* sc3;   // [3]
+    const float* sh3;   // [3]
+    const float* wp_t;  // [2A][A]       policy_fc weight, transposed (input-major)
+    const float* bp;    // [A]
+    const float* w1_t;  // [A][planes]   value_fc1 weight, transposed
+    const float* b1;    // [planes]
+    const float* w2;    // [planes]      value_fc2
+    const float* b2;    // [1]
+};
+
+__device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, t) : v + t;
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wid] = v;
+    __syncthreads();
+    float r = s_red[0];
+    for (int i = 1; i < static_cast<int>(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, s_red[i]) : r + s_red[i];
+    return r;
+}
+
+// One (16 cells x 16 output channels) tile of one board's 3x3 conv, computed by NW waves:
+// each takes 9/NW taps (that share of the K loop), the partial tiles are summed through LDS.
+// A single wave per tile is bound by its own in-order chain of 144 loads; nine waves cut that
+// chain to 16 (best for one board), three to 48 (best for a few dozen).
+// Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
+// All NW waves of the workgroup must call; s_red holds (NW-1) x 64 x 4 floats.
+template <int BW, int NCQG, int NW>
+__device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, const float4* __restrict__ wt,
+                                                const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                                const float4* res, float4* out, int CQI, int COUT, int relu_res,
+                                                int ct, int ctile, int board, float* s_red) {
+    constexpr int A = BW * BW;
+    constexpr int TP = 9 / NW;
+    const int lane = threadIdx.x & 63;
+    const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int kq = lane >> 4, ci = lane & 15;
+    const int cell = ctile * 16 + ci;
+    const int cy = cell / BW, cx = cell - cy * BW;
+    const float4* xb = in + static_cast<size_t>(board) * A * CQI;
+    // four independent accumulator chains (one chain would pay the 40-cycle dependent-MFMA latency
+    // on every instruction)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    float4 rx[TP][NCQG], rw[TP][NCQG];
+    auto load_tap = [&](int tap, float4 (&X)[NCQG], float4 (&W)[NCQG]) {
+        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
+        const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
+        const float4* xp = xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
+        const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
+#pragma unroll
+        for (int cqg = 0; cqg < NCQG; ++cqg) {
+            float4 x = xp[cqg * 4];
+            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            X[cqg] = x;
+            W[cqg] = wp[static_cast<size_t>(cqg) * 4 * COUT];
+        }
+    };
+    auto compute_tap = [&](const float4 (&X)[NCQG], const float4 (&W)[NCQG]) {
+#pragma unroll
+        for (int cqg = 0; cqg < NCQG; ++cqg) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].x, X[cqg].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].y, X[cqg].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].z, X[cqg].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].w, X[cqg].w, acc3, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < TP; ++j) load_tap(TP * w3 + j, rx[j], rw[j]);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+    if (w3 > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[((w3 - 1) * 64 + lane) * 4 + r] = acc[r];
+    }
+    __syncthreads();
+    if (w3 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = acc[r];
+#pragma unroll
+            for (int k = 0; k < NW - 1; ++k) t += s_red[(k * 64 + lane) * 4 + r];
+            acc[r] = t;
+        }
+        // D row = cout 4*kq + reg, col = cell ci
+        if (cell < A) {
+            const int cqo = ct * 4 + kq;
+            const float4 sc = scale[cqo], sh = shift[cqo];
+            const size_t o = (static_cast<size_t>(board) * A + cell) * (COUT >> 2) + cqo;
+            float4 v;
+            v.x = fmaf(acc[0], sc.x, sh.x); v.y = fmaf(acc[1], sc.y, sh.y);
+            v.z = fmaf(acc[2], sc.z, sh.z); v.w = fmaf(acc[3], sc.w, sh.w);
+            if (relu_res) {
+                const float4 rr = res[o];
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            out[o] = v;
+        }
+    }
+}
+
+// LDS floats heads_board_dev needs
+__host__ __device__ inline size_t heads_lds_floats(int A, int planes) {
+    return static_cast<size_t>(3) * planes + 3 * A + 6 * A + 4 * A + 2 * planes + planes + 16;
+}
+
+// Policy and value heads of ONE board (model.py:34-73) by one workgroup of any size >= 64:
+// 1x1 convs + BN + ReLU -> flatten in NCHW order (c*A + cell, the reference's .view) ->
+// policy_fc + softmax, value_fc1 + ReLU + value_fc2 + tanh. Every dot product is cut into
+// slices so that all threads carry a short, independent chain of loads (the weight matrices come
+// from L2: 52 KB + 41 KB at 9x9), partial sums meet in LDS.
+// act = this board's activations [A][planes/4]; policy -> [A], value -> [1]. All threads must call.
+__device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float4* __restrict__ act,
+                                                float* __restrict__ policy, float* __restrict__ value, int A,
+                                                int planes, float* s_mem) {
+    constexpr int KS = 2;   // K slices of the 1x1 convs
+    constexpr int NPS = 4;  // slices of the 2A-long policy_fc dot products
+    constexpr int NVS = 2;  // slices of the A-long value_fc1 dot products
+    float* s_w3 = s_mem;                 // [3*planes]
+    float* s_h = s_w3 + 3 * planes;      // [3A]
+    float* s_hp = s_h + 3 * A;           // [KS][3A]
+    float* s_part = s_hp + KS * 3 * A;   // [NPS][A]
+    float* s_vpart = s_part + NPS * A;   // [NVS][planes]
+    float* s_hid = s_vpart + NVS * planes;  // [planes]
+    float* s_red = s_hid + planes;       // [16]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int CQ = planes >> 2;
+    for (int i = tid; i < 3 * planes; i += nt) s_w3[i] = h.w3[i];
+    __syncthreads();
+    // 1x1 convs: (K slice, output channel, cell) per thread
+    const int cqs = (CQ + KS - 1) / KS;
+    for (int i = tid; i < KS * 3 * A; i += nt) {
+        const int ks = i / (3 * A), r = i - ks * 3 * A;
+        const int c = r / A, cell = r - c * A;
+        const int q0 = ks * cqs, q1 = min(CQ, q0 + cqs);
+        const float4* xp = act + static_cast<size_t>(cell) * CQ;
+        const float* w = s_w3 + c * planes;
+        float a0 = 0.f, a1 = 0.f;
+        int cq = q0;
+        for (; cq + 1 < q1; cq += 2) {
+            const float4 x = xp[cq], y = xp[cq + 1];
+            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
+            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
+            a1 = fmaf(y.x, w[4 * cq + 4], a1); a1 = fmaf(y.y, w[4 * cq + 5], a1);
+            a1 = fmaf(y.z, w[4 * cq + 6], a1); a1 = fmaf(y.w, w[4 * cq + 7], a1);
+        }
+        if (cq < q1) {
+            const float4 x = xp[cq];
+            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
+            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
+        }
+        s_hp[i] = a0 + a1;
+    }
+    __syncthreads();
+    for (int r = tid; r < 3 * A; r += nt) {
+        const int c = r / A;
+        float t = s_hp[r];
+#pragma unroll
+        for (int ks = 1; ks < KS; ++ks) t += s_hp[ks * 3 * A + r];
+        s_h[r] = fmaxf(fmaf(t, h.sc3[c], h.sh3[c]), 0.f);
+    }
+    __syncthreads();
+    // policy_fc (NPS slices per output) and value_fc1 (NVS slices per hidden unit) in one sweep
+    const int np_items = NPS * A, nv_items = NVS * planes;
+    const int pslice = (2 * A + NPS - 1) / NPS, vslice = (A + NVS - 1) / NVS;
+    for (int i = tid; i < np_items + nv_items; i += nt) {
+        float acc = 0.f;
+        if (i < np_items) {
+            const int part = i / A, a = i - part * A;
+            const int j0 = part * pslice, j1 = min(2 * A, j0 + pslice);
+            const float* wcol = h.wp_t + a;
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) acc = fmaf(wcol[static_cast<size_t>(j) * A], s_h[j], acc);
+            s_part[i] = acc;
+        } else {
+            const int k = i - np_items;
+            const int part = k / planes, o = k - part * planes;
+            const int j0 = part * vslice, j1 = min(A, j0 + vslice);
+            const float* wcol = h.w1_t + o;
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) acc = fmaf(wcol[static_cast<size_t>(j) * planes], s_h[2 * A + j], acc);
+            s_vpart[k] = acc;
+        }
+    }
+    __syncthreads();
+    float lmax = -3.0e38f;
+    for (int a = tid; a < A; a += nt) {
+        float l = h.bp[a];
+#pragma unroll
+        for (int q = 0; q < NPS; ++q) l += s_part[q * A + a];
+        s_part[a] = l;
+        lmax = fmaxf(lmax, l);
+    }
+    for (int o = tid; o < planes; o += nt) {
+        float t = h.b1[o];
+#pragma unroll
+        for (int q = 0; q < NVS; ++q) t += s_vpart[q * planes + o];
+        s_hid[o] = fmaxf(t, 0.f);
+    }
+    lmax = block_reduce(lmax, s_red, true);   // (its barriers also publish s_part / s_hid)
+    float lsum = 0.f;
+    for (int a = tid; a < A; a += nt) {
+        const float ex = expf(s_part[a] - lmax);
+        s_part[a] = ex;
+        lsum += ex;
+    }
+    lsum = block_reduce(lsum, s_red, false);
+    for (int a = tid; a < A; a += nt) policy[a] = s_part[a] / lsum;
+    float part = 0.f;
+    for (int o = tid; o < planes; o += nt) part = fmaf(h.w2[o], s_hid[o], part);
+    part = block_reduce(part, s_red, false);
+    if (tid == 0) value[0] = tanhf(part + h.b2[0]);
+}
+
+}  // namespace ao

@@ -19,557 +19,22 @@
 // Arithmetic contract: fp64 PUCT evaluated left to right with no
 // FMA contraction (explicit __dmul_rn/__ddiv_rn/__dadd_rn), sqrt(total_n) from a host-built
 // table of correctly rounded values, fp32 w/q with correctly rounded add/divide.
-#include "engine_types.hpp"
+#include "tree_device.hpp"
 
 namespace ao {
 
-// ----------------------------------------------------------------------------------------------
-// wave helpers (wavefront = 64 lanes)
-// ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
-
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-
-__device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
-
-// index of the r-th (0-based) set bit of m, m has more than r bits set
-__device__ __forceinline__ int nth_set_bit(uint64_t m, int r) {
-    const bool mine = ((m >> lane_id()) & 1ull) && (__popcll(m & lanes_below()) == r);
-    const uint64_t hit = __ballot(mine);
-    return __ffsll(static_cast<long long>(hit)) - 1;
-}
-
-// ----------------------------------------------------------------------------------------------
-// positions
-// ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bb_test(const uint64_t* bb, int cell) {
-    return (bb[cell >> 6] >> (cell & 63)) & 1ull;
-}
-
-__device__ __forceinline__ bool pos_occupied(const Pos& s, int cell) {
-    return ((s.bb[0][cell >> 6] | s.bb[1][cell >> 6]) >> (cell & 63)) & 1ull;
-}
-
-// env step / get_board: stone colour alternates, black first (utils.py:171-179)
-__device__ __forceinline__ void pos_place(Pos& s, int cell) {
-    const int colour = s.ply & 1;
-    s.bb[colour][cell >> 6] |= 1ull << (cell & 63);
-#pragma unroll
-    for (int i = kLastMoves - 1; i > 0; --i) s.last[i] = s.last[i - 1];
-    s.last[0] = static_cast<uint8_t>(cell);
-    s.ply = static_cast<int16_t>(s.ply + 1);
-}
-
-__device__ __forceinline__ void pos_clear(Pos& s) {
-#pragma unroll
-    for (int i = 0; i < kBBWords; ++i) { s.bb[0][i] = 0; s.bb[1][i] = 0; }
-    s.ply = 0;
-    s.nchild = 0;
-#pragma unroll
-    for (int i = 0; i < kLastMoves; ++i) s.last[i] = 0xFF;
-    s.pad_ = 0;
-}
-
-// Terminal test of the position reached by the stone just placed on `cell`
-// (wave-uniform; all 64 lanes must call). Returns the reference's win_index:
-// 0 playing, 1 black, 2 white, 3 draw (utils.py:30-59). Equivalent to the reference's window
-// scan because the parent position was not terminal: only a line through the new stone can be
-// new, and any run >= win_mark contains a window of exactly win_mark (overlines count).
-__device__ __forceinline__ int win_after_move(const Pos& s, int cell, int B, int win_mark) {
-    const int mover = (s.ply - 1) & 1;
-    const int lane = lane_id();
-    // lane l < 32: direction l>>3, offset index l&7 -> offsets -4..-1, +1..+4
-    const int dir = (lane >> 3) & 3;
-    const int j = lane & 7;
-    const int off = j < 4 ? j - 4 : j - 3;
-    const int dr = (dir == 0) ? 0 : 1;
-    const int dc = (dir == 0) ? 1 : (dir == 1) ? 0 : (dir == 2) ? 1 : -1;
-    const int r = cell / B + off * dr;
-    const int c = cell % B + off * dc;
-    bool bit = false;
-    if (lane < 32 && r >= 0 && r < B && c >= 0 && c < B) bit = bb_test(s.bb[mover], r * B + c);
-    const uint64_t m = __ballot(bit);
-    bool won = false;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const unsigned m8 = static_cast<unsigned>((m >> (8 * d)) & 0xFFu);
-        int run = 1;
-        // offsets -1,-2,-3,-4 are bits 3,2,1,0 ; +1..+4 are bits 4..7
-        for (int b = 3; b >= 0 && ((m8 >> b) & 1u); --b) ++run;
-        for (int b = 4; b < 8 && ((m8 >> b) & 1u); ++b) ++run;
-        won = won || (run >= win_mark);
-    }
-    if (won) return mover + 1;
-    if (s.ply == B * B) return 3;
-    return 0;
-}
-
-// ----------------------------------------------------------------------------------------------
-// per-game MT19937 stream on the device (numpy legacy RandomState)
-// ----------------------------------------------------------------------------------------------
-struct MtDev {
-    uint32_t* g_mt;
-    int32_t* g_pos;
-    uint32_t* lds;  // [624]
-    int pos;
-    bool in_lds;
-
-    __device__ void open(uint32_t* mt_row, int32_t* pos_ptr, uint32_t* lds_buf) {
-        g_mt = mt_row;
-        g_pos = pos_ptr;
-        lds = lds_buf;
-        pos = *pos_ptr;
-        in_lds = false;
-    }
-
-    // regenerate all 624 words (wave-parallel through LDS), write the state back to HBM
-    __device__ void twist() {
-        const int lane = lane_id();
-        if (!in_lds) {
-            for (int i = lane; i < 624; i += 64) lds[i] = g_mt[i];
-            __syncthreads();
-        }
-        constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MAT = 0x9908b0dfu;
-        for (int k0 = 0; k0 < 227; k0 += 64) {
-            const int k = k0 + lane;
-            uint32_t v = 0;
-            if (k < 227) {
-                const uint32_t y = (lds[k] & UP) | (lds[k + 1] & LO);
-                v = lds[k + 397] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
-            }
-            __syncthreads();
-            if (k < 227) lds[k] = v;
-            __syncthreads();
-        }
-        for (int k0 = 227; k0 < 623; k0 += 64) {
-            const int k = k0 + lane;
-            uint32_t v = 0;
-            if (k < 623) {
-                const uint32_t y = (lds[k] & UP) | (lds[k + 1] & LO);
-                v = lds[k - 227] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
-            }
-            __syncthreads();
-            if (k < 623) lds[k] = v;
-            __syncthreads();
-        }
-        if (lane == 0) {
-            const uint32_t y = (lds[623] & UP) | (lds[0] & LO);
-            lds[623] = lds[396] ^ (y >> 1) ^ ((y & 1u) ? MAT : 0u);
-        }
-        __syncthreads();
-        for (int i = lane; i < 624; i += 64) g_mt[i] = lds[i];
-        in_lds = true;
-        pos = 0;
-    }
-
-    __device__ uint32_t next32() {  // wave-uniform
-        if (pos >= 624) twist();
-        uint32_t y = in_lds ? lds[pos] : g_mt[pos];
-        ++pos;
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
-    }
-
-    // np.random.choice(k) == randint(0, k): masked rejection on 32-bit words; k == 1 draws nothing
-    __device__ int below(int k) {
-        if (k <= 1) return 0;
-        uint32_t rng = static_cast<uint32_t>(k - 1);
-        uint32_t mask = rng;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        uint32_t v;
-        do { v = next32() & mask; } while (v > rng);
-        return static_cast<int>(v);
-    }
-
-    // np.random.random_sample(): 53-bit double from two words
-    __device__ double next_double() {
-        const uint32_t a = next32() >> 5;
-        const uint32_t b = next32() >> 6;
-        return __ddiv_rn(__dadd_rn(__dmul_rn(static_cast<double>(a), 67108864.0), static_cast<double>(b)),
-                         9007199254740992.0);
-    }
-
-    __device__ void close() {
-        if (lane_id() == 0) *g_pos = pos;
-    }
-};
-
-// ----------------------------------------------------------------------------------------------
-// get_state_pt (utils.py:139-168): planes [X_{k-C+2} .. X_k, colour], X_j = stones of the player
-// who made move j as they stood after move j. Written into the evaluation batch.
-// ----------------------------------------------------------------------------------------------
-template <int NCH>
-__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const Pos& s) {
-    const int lane = lane_id();
-    const int k = s.ply;
-    const int stm = k & 1;           // 0: black to move
-    const float colour = (stm == 0) ? 1.f : 0.f;
-    const int C = p.C;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int cell = lane + 64 * c;
-        if (cell >= p.A) continue;
-        float pl[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) pl[i] = 0.f;
-        for (int j = 0; j <= C - 2; ++j) {
-            // X_{k-j}: mover of move k-j is the opponent of the side to move when j is even
-            float v = 0.f;
-            if (k - j >= 1) {
-                const int col = (j & 1) ? stm : (stm ^ 1);
-                bool on = bb_test(s.bb[col], cell);
-                for (int i = j - 2; i >= 0; i -= 2) on = on && (s.last[i] != cell);
-                v = on ? 1.f : 0.f;
-            }
-            pl[C - 2 - j] = v;
-        }
-        pl[C - 1] = colour;
-        if (p.batch_nchw) {
-            for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = pl[q];
-        }
-        if (p.batch_il) {
-            const size_t grp = static_cast<size_t>(g / p.il_group);
-            const int b = g % p.il_group;
-            for (int cq = 0; cq < p.nchq; ++cq) {
-                float4 v4 = make_float4(pl[4 * cq], pl[4 * cq + 1], pl[4 * cq + 2], pl[4 * cq + 3]);
-                float4* dst = reinterpret_cast<float4*>(p.batch_il) +
-                              (((grp * p.A + cell) * p.nchq + cq) * p.il_group + b);
-                *dst = v4;
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
-// k_select
-// ----------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(64) void k_select(TreeParams p) {
     __shared__ uint32_t s_mt[624];
-    const int g = blockIdx.x;
-    const int lane = lane_id();
-    if ((p.active && !p.active[g]) || p.sims_done[g] >= p.sims_target[g]) {
-        if (lane == 0) p.leaf_status[g] = LS_IDLE;
-        return;
-    }
-    MtDev mt;
-    mt.open(p.mt + static_cast<size_t>(g) * 624, p.mtpos + g, s_mt);
-
-    const int arena = p.cur[g];
-    int node = p.root_node[g];
-    int depth = 0;
-    int status = LS_EXPAND_ROOT;
-    unsigned levels = 0, ties = 0;
-    Pos lp;
-    if (node < 0) {
-        lp = p.rootpos[g];
-    } else {
-        for (;;) {
-            const size_t slot = node_slot(p, arena, g, node);
-            const Pos m = p.meta[slot];
-            const int L = m.nchild;
-            const size_t eb = slot * p.Ap;
-            int n[NCH];
-            int tot = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int e = lane + 64 * c;
-                n[c] = (e < L) ? p.N[eb + e] : 0;
-                tot += n[c];
-            }
-            tot = wave_sum_i(tot);
-            // np.sqrt(total_n): correctly rounded table (total_n is an exact integer)
-            const double sq = p.sqrt_lut[tot < p.sqrt_lut_n ? tot : p.sqrt_lut_n - 1];
-            double sc[NCH];
-            double mx = -1.0e300;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int e = lane + 64 * c;
-                sc[c] = -1.0e300;
-                if (e < L) {
-                    const double q = static_cast<double>(p.Q[eb + e]);
-                    const double pr = p.P[eb + e];
-                    // u = c_puct * p * sqrt(total_n) / (n + 1)   (agents.py:158, left to right)
-                    double t = __dmul_rn(p.c_puct, pr);
-                    t = __dmul_rn(t, sq);
-                    const double u = __ddiv_rn(t, static_cast<double>(n[c] + 1));
-                    sc[c] = __dadd_rn(q, u);
-                }
-                mx = sc[c] > mx ? sc[c] : mx;
-            }
-            mx = wave_max_d(mx);
-            // every exact-equal maximum, in child order; uniform pick (agents.py:161-163)
-            uint64_t tm[NCH];
-            int k = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int e = lane + 64 * c;
-                tm[c] = __ballot(e < L && sc[c] == mx);
-                k += __popcll(tm[c]);
-            }
-            int r = 0;
-            if (k > 1) { r = mt.below(k); ++ties; }
-            int esel = -1;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int cnt = __popcll(tm[c]);
-                if (esel < 0) {
-                    if (r < cnt) esel = 64 * c + nth_set_bit(tm[c], r);
-                    else r -= cnt;
-                }
-            }
-            if (esel < 0 || depth >= p.maxd) {  // cannot happen for a consistent tree
-                if (lane == 0) { atomicOr(&p.err[g], ERR_PATH); p.leaf_status[g] = LS_IDLE; }
-                mt.close();
-                return;
-            }
-            if (lane == 0) {
-                p.path_node[static_cast<size_t>(g) * p.maxd + depth] = node;
-                p.path_edge[static_cast<size_t>(g) * p.maxd + depth] = static_cast<int16_t>(esel);
-            }
-            ++depth;
-            ++levels;
-            const int ch = p.CH[eb + esel];
-            if (ch >= 0) { node = ch; continue; }
-            if (ch == CH_TERMINAL) { status = LS_TERMINAL; break; }
-            // first visit of this child: build its position, test for the end of the game
-            lp = m;
-            const int a = p.ACT[eb + esel];
-            pos_place(lp, a);
-            const int w = win_after_move(lp, a, p.B, p.win_mark);
-            if (w != 0) {
-                status = LS_TERMINAL;
-                if (lane == 0) p.CH[eb + esel] = CH_TERMINAL;
-            } else {
-                status = LS_EXPAND;
-            }
-            break;
-        }
-    }
-    if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
-        lp.nchild = 0;
-        if (lane == 0) p.leaf_pos[g] = lp;
-        encode_planes<NCH>(p, g, lp);
-    }
-    if (lane == 0) {
-        p.leaf_status[g] = status;
-        p.path_len[g] = depth;
-        // per-game counters (a shared word would serialise 4 x G atomics per simulation)
-        unsigned* st = p.stats + static_cast<size_t>(g) * 4;
-        st[0] += levels;
-        st[1] += ties;
-        st[(status == LS_TERMINAL) ? 2 : 3] += 1u;
-    }
-    mt.close();
+    select_game<NCH>(p, blockIdx.x, s_mt);
 }
 
-// ----------------------------------------------------------------------------------------------
-// utils.legal_actions order (utils.py:22-27) = iteration order of a CPython 3.10 set difference.
-// Ascending unless the result set's final hash table is smaller than its largest key
-// (SURVEY.md Q5); that case is emulated on lane 0 (set_add_entry / set_table_resize).
-// Writes the ordered actions to s_ord, returns their count (wave-uniform).
-// ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ int set_probe(const int16_t* tab, int mask, int key) {
-    unsigned perturb = static_cast<unsigned>(key);
-    unsigned i = static_cast<unsigned>(key) & static_cast<unsigned>(mask);
-    for (;;) {
-        int probes = (i + 9u <= static_cast<unsigned>(mask)) ? 9 : 0;  // LINEAR_PROBES
-        unsigned e = i;
-        do {
-            if (tab[e] < 0) return static_cast<int>(e);
-            ++e;
-        } while (probes--);
-        perturb >>= 5;  // PERTURB_SHIFT
-        i = (i * 5u + 1u + perturb) & static_cast<unsigned>(mask);
-    }
-}
-
-template <int NCH>
-__device__ int legal_order(const Pos& s, int A, uint8_t* s_ord, int16_t* s_tab /*[2][128]*/) {
-    const int lane = lane_id();
-    int L = 0;
-    int maxkey = -1;
-    bool legal[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int cell = lane + 64 * c;
-        legal[c] = (cell < A) && !pos_occupied(s, cell);
-        const uint64_t m = __ballot(legal[c]);
-        if (legal[c]) s_ord[L + __popcll(m & lanes_below())] = static_cast<uint8_t>(cell);
-        if (m) maxkey = 64 * c + 63 - __clzll(static_cast<long long>(m));
-        L += __popcll(m);
-    }
-    __syncthreads();
-    const int nstones = s.ply;
-    if ((A >> 2) > nstones) return L;  // set_copy_and_difference: ascending
-    const int tsize = (L <= 4) ? 8 : (L <= 18) ? 32 : (L <= 76) ? 128 : 512;
-    if (maxkey < tsize) return L;      // every key sits in its own slot: ascending
-    if (lane == 0) {
-        int16_t* tab = s_tab;
-        int16_t* alt = s_tab + 128;
-        int mask = 7, fill = 0;
-        for (int i = 0; i < 8; ++i) tab[i] = -1;
-        for (int idx = 0; idx < L; ++idx) {  // `so` iterates ascending; s_ord holds that order
-            const int key = s_ord[idx];
-            tab[set_probe(tab, mask, key)] = static_cast<int16_t>(key);
-            ++fill;
-            if (fill * 5 >= mask * 3) {
-                const int minused = fill * 4;
-                int ns = 8;
-                while (ns <= minused) ns <<= 1;
-                for (int i = 0; i < ns; ++i) alt[i] = -1;
-                for (int i = 0; i <= mask; ++i)
-                    if (tab[i] >= 0) alt[set_probe(alt, ns - 1, tab[i])] = tab[i];
-                int16_t* t = tab; tab = alt; alt = t;
-                mask = ns - 1;
-            }
-        }
-        int cnt = 0;
-        for (int i = 0; i <= mask; ++i)
-            if (tab[i] >= 0) s_ord[cnt++] = static_cast<uint8_t>(tab[i]);
-    }
-    __syncthreads();
-    return L;
-}
-
-// numpy pairwise fp64 sum of a length-n vector (8 <= n <= 256), DOUBLE_pairwise_sum.
-// All 64 lanes call; lanes 0-7 reduce the left block, 8-15 the right block (n > 128).
-__device__ __forceinline__ double pairwise_block(const double* a, int n, int l8) {
-    double r = a[l8];
-    const int lim = n - (n % 8);
-    for (int i = 8; i < lim; i += 8) r = __dadd_rn(r, a[i + l8]);
-    r = __dadd_rn(r, __shfl_xor(r, 1));
-    r = __dadd_rn(r, __shfl_xor(r, 2));
-    r = __dadd_rn(r, __shfl_xor(r, 4));
-    for (int i = lim; i < n; ++i) r = __dadd_rn(r, a[i]);
-    return r;
-}
-
-__device__ __forceinline__ double pairwise_sum_dev(const double* a, int n) {
-    const int lane = lane_id();
-    const int l8 = lane & 7;
-    const int grp = lane >> 3;
-    if (n <= 128) {
-        const double r = pairwise_block(a, n, l8);
-        return __shfl(r, 0);
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const double* base = (grp == 1) ? a + n2 : a;
-    const int len = (grp == 1) ? n - n2 : n2;
-    const double r = pairwise_block(base, len, l8);
-    const double left = __shfl(r, 0);
-    const double right = __shfl(r, 8);
-    return __dadd_rn(left, right);
-}
-
-// ----------------------------------------------------------------------------------------------
-// k_expand_backup
-// ----------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(64) void k_expand_backup(TreeParams p) {
     __shared__ uint8_t s_ord[256];
     __shared__ double s_prior[256];
     __shared__ int16_t s_tab[256];
-    const int g = blockIdx.x;
-    const int lane = lane_id();
-    const int status = p.leaf_status[g];
-    if (status == LS_IDLE) return;
-    const int arena = p.cur[g];
-    const int depth = p.path_len[g];
-    float v = 0.f;
-    if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
-        const int newn = p.nodes_used[g];
-        if (newn >= p.cap) {
-            if (lane == 0) { atomicOr(&p.err[g], ERR_NODE_CAP); p.sims_done[g] = p.sims_target[g]; }
-            return;
-        }
-        Pos lp = p.leaf_pos[g];
-        const int L = legal_order<NCH>(lp, p.A, s_ord, s_tab);
-        // prior_prob = zeros(A); prior_prob[a] = policy[a] for legal a (agents.py:183-187)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int cell = lane + 64 * c;
-            if (cell < p.A)
-                s_prior[cell] = pos_occupied(lp, cell)
-                                    ? 0.0
-                                    : static_cast<double>(p.policy[static_cast<size_t>(g) * p.A + cell]);
-        }
-        __syncthreads();
-        const double sum = pairwise_sum_dev(s_prior, p.A);  // prior_prob.sum() (agents.py:189)
-        const bool add_noise = p.noise && status == LS_EXPAND_ROOT;  // agents.py:191-204
-        const size_t slot = node_slot(p, arena, g, newn);
-        const size_t eb = slot * p.Ap;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int i = lane + 64 * c;
-            if (i < L) {
-                const int a = s_ord[i];
-                double pr = __ddiv_rn(s_prior[a], sum);
-                if (add_noise) {
-                    const double t1 = __dmul_rn(0.75, pr);
-                    const double t2 = __dmul_rn(0.25, p.noise_buf[static_cast<size_t>(g) * p.Ap + i]);
-                    pr = __dadd_rn(t1, t2);
-                }
-                p.N[eb + i] = 0;
-                p.W[eb + i] = 0.f;
-                p.Q[eb + i] = 0.f;
-                p.P[eb + i] = pr;
-                p.CH[eb + i] = CH_UNVISITED;
-                p.ACT[eb + i] = static_cast<uint8_t>(a);
-            }
-        }
-        if (lane == 0) {
-            lp.nchild = static_cast<int16_t>(L);
-            p.meta[slot] = lp;
-            p.nodes_used[g] = newn + 1;
-            if (status == LS_EXPAND) {
-                const int pn = p.path_node[static_cast<size_t>(g) * p.maxd + depth - 1];
-                const int pe = p.path_edge[static_cast<size_t>(g) * p.maxd + depth - 1];
-                p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
-            } else {
-                p.root_node[g] = newn;
-            }
-        }
-        v = p.value[g];
-    }
-    // backup (agents.py:223-239): the edge into the leaf gets -v (or +1 for a terminal leaf,
-    // draws included), the sign alternates towards the root. The root's own record is not kept.
-    const bool terminal = (status == LS_TERMINAL);
-    for (int d = lane; d < depth; d += 64) {
-        const int nd = p.path_node[static_cast<size_t>(g) * p.maxd + d];
-        const int e = p.path_edge[static_cast<size_t>(g) * p.maxd + d];
-        const int cnt = depth - 1 - d;
-        float s;
-        if (terminal) s = (cnt & 1) ? -1.f : 1.f;
-        else s = (cnt & 1) ? v : -v;
-        const size_t idx = node_slot(p, arena, g, nd) * p.Ap + e;
-        const int n = p.N[idx] + 1;
-        const float w = __fadd_rn(p.W[idx], s);
-        p.N[idx] = n;
-        p.W[idx] = w;
-        p.Q[idx] = __fdiv_rn(w, static_cast<float>(n));
-    }
-    if (lane == 0) p.sims_done[g] = p.sims_done[g] + 1;
+    expand_backup_game<NCH>(p, blockIdx.x, s_ord, s_prior, s_tab);
 }
 
 // ----------------------------------------------------------------------------------------------
