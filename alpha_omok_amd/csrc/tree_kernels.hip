@@ -37,6 +37,21 @@ __global__ __launch_bounds__(64) void k_expand_backup(TreeParams p) {
     expand_backup_game<NCH>(p, blockIdx.x, s_ord, s_prior, s_tab);
 }
 
+// expansion + backup of simulation i, then selection + input planes of simulation i+1, in one
+// launch: the fused search loop (ao_search) is select | net | expand_select | net | ... -- one
+// launch fewer per simulation, which matters when a handful of games make every kernel a few
+// microseconds long. The trailing selection idles by itself once a game has all its simulations.
+template <int NCH>
+__global__ __launch_bounds__(64) void k_expand_select(TreeParams p) {
+    __shared__ uint32_t s_mt[624];
+    __shared__ uint8_t s_ord[256];
+    __shared__ double s_prior[256];
+    __shared__ int16_t s_tab[256];
+    expand_backup_game<NCH>(p, blockIdx.x, s_ord, s_prior, s_tab);
+    wsync();
+    select_game<NCH>(p, blockIdx.x, s_mt);
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_begin_move: re-noise the children of an inherited, expanded root (agents.py:93-103)
 // ----------------------------------------------------------------------------------------------
@@ -360,6 +375,9 @@ void launch_select(const TreeParams& p, hipStream_t s) {
 }
 void launch_expand_backup(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_backup<NCH>, dim3(p.G), dim3(64), 0, s, p));
+}
+void launch_expand_select(const TreeParams& p, hipStream_t s) {
+    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_select<NCH>, dim3(p.G), dim3(64), 0, s, p));
 }
 void launch_begin_move(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_begin_move<NCH>, dim3(p.G), dim3(64), 0, s, p));
