@@ -759,7 +759,7 @@ int net_check(const ao_net* n, int board, int inplanes, int device, std::string*
 
 // Execution plan for a batch of `boards` positions: which trunk runs and which interleaved input
 // layout (boards per group, channel quads) it expects.
-//   3  per-board NHWC, cells as MFMA N      -- up to ~320 boards (latency path)
+//   3  per-board NHWC, cells as MFMA N      -- up to ~160 9x9 boards (13k cells; latency path)
 //   2  group-resident trunk, 16 boards/WG   -- >= 192 groups: one workgroup per CU for the whole net
 //   4  one launch per layer over (16-board group x row chunk) -- everything in between
 //   1  one launch per layer over 32-board groups x board rows (first-generation kernel, explicit only)
@@ -767,7 +767,9 @@ int pick_mode_public(const ao_net* n, int boards);
 static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     int mode = n->mode;
     const int g16 = (boards + 15) / 16;
-    if (mode == 0) mode = (boards <= 320) ? 3 : (g16 >= 192 ? 2 : 4);
+    // measured cross-over of the per-board path and the row-chunked layers: 128 boards 529 vs 676 us,
+    // 256 boards 979 vs 676 us per simulation (9x9, 4 blocks)
+    if (mode == 0) mode = (static_cast<long>(boards) * n->A <= 13000) ? 3 : (g16 >= 192 ? 2 : 4);
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
     int nch = 1;
     if (mode == 4) {

@@ -14,6 +14,7 @@ ap.add_argument("--board", type=int, default=9)
 ap.add_argument("--blocks", type=int, default=4)
 ap.add_argument("--planes", type=int, default=128)
 ap.add_argument("--sims", type=int, default=400)
+ap.add_argument("--mode", type=int, default=0, help="ao_net_set_mode: 0 auto, 1, 2, 3, 4")
 a = ap.parse_args()
 import torch
 from alpha_omok_amd.pvnet import PVNet
@@ -21,6 +22,7 @@ torch.manual_seed(0)
 model = PVNet(a.blocks, 5, a.planes, a.board)   # PyTorch default init, as bench.py
 model.eval()
 net = model.to_native(0)
+net.set_mode(a.mode)
 eng = Engine(a.board, a.sims, 5, games=a.games, noise=True)
 eng.seed_all(np.arange(a.games))
 tau = np.ones(a.games, np.int8)
@@ -31,5 +33,5 @@ for _ in range(a.moves):
     eng.play()
 eng.sync()
 dt = time.perf_counter() - t0
-print("games %d: %.2f ms/move, %.1f us/sim, %.1f move-decisions/s" % (
-    a.games, dt / a.moves * 1e3, dt / a.moves / a.sims * 1e6, a.games * a.moves / dt))
+print("mode %d games %d: %.2f ms/move, %.1f us/sim, %.1f move-decisions/s" % (
+    a.mode, a.games, dt / a.moves * 1e3, dt / a.moves / a.sims * 1e6, a.games * a.moves / dt))
