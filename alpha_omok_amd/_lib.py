@@ -60,6 +60,15 @@ SYMBOLS = {
     "ao_net_set_mode": (C.c_int, [_vp, C.c_int]),
     "ao_net_conv_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_net_dominant_kernel": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _f64p]),
+    "ao_replay_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _P(_vp)]),
+    "ao_replay_destroy": (None, [_vp]),
+    "ao_replay_last_error": (C.c_char_p, [_vp]),
+    "ao_replay_size": (C.c_int64, [_vp]),
+    "ao_replay_capacity": (C.c_int64, [_vp]),
+    "ao_replay_clear": (C.c_int, [_vp]),
+    "ao_replay_extend": (C.c_int, [_vp, _P(C.c_float), _f64p, _P(C.c_float), C.c_int64, C.c_int, _vp]),
+    "ao_replay_gather": (C.c_int, [_vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
+    "ao_replay_read": (C.c_int, [_vp, C.c_int64, C.c_int64, _f64p, _f64p, _f64p]),
 }
 
 _lib = None

@@ -15,6 +15,9 @@ Differences by design:
     np.random state is used, which reproduces `np.random.seed(s); main.self_play(1)` exactly.
   * under torch.distributed (one process per GPU) episodes are sharded e % world == rank and
     train() all-reduces the flattened gradient (parallel.py).
+  * configure(device_replay=True) keeps rep_memory in HBM (replay.DeviceReplay): the eight
+    symmetries are made by a HIP kernel and train() gathers its mini-batches on the device. The
+    entries, their order and the batches drawn under a given `random` state are the reference's.
 """
 import logging
 import random
@@ -64,10 +67,10 @@ _episodes_played = 0
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
-              model=None, gpu=None, noise=True):
+              model=None, gpu=None, noise=True, device_replay=False):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
-    global _engine, _evaluator, _episodes_played
+    global _engine, _evaluator, _episodes_played, rep_memory
     import torch
     from .pvnet import PVNet
     BOARD_SIZE = board_size or BOARD_SIZE
@@ -92,6 +95,11 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     _engine = None
     _evaluator = Evaluator(gpu)
     _episodes_played = 0
+    if device_replay:
+        from .replay import DeviceReplay
+        rep_memory = DeviceReplay(BOARD_SIZE, IN_PLANES, MEMORY_SIZE, device=gpu)
+    elif not isinstance(rep_memory, deque):
+        rep_memory = deque(maxlen=MEMORY_SIZE)
     return Agent
 
 
@@ -188,7 +196,10 @@ def self_play(n_selfplay, seeds=None):
             root = root + (a,)
     _episodes_played += n_selfplay
     Agent.reset()
-    rep_memory.extend(utils.augment_dataset(cur_memory, BOARD_SIZE))
+    if hasattr(rep_memory, "extend_augmented"):
+        rep_memory.extend_augmented(cur_memory)           # symmetries made on the device
+    else:
+        rep_memory.extend(utils.augment_dataset(cur_memory, BOARD_SIZE))
 
 
 def train(n_epochs, n_iter):
@@ -199,14 +210,20 @@ def train(n_epochs, n_iter):
     import torch
     Agent.model.train()
     n = min(BATCH_SIZE * len(cur_memory), len(rep_memory))
-    train_memory = random.sample(list(rep_memory), n)
+    on_device = hasattr(rep_memory, "batch")
+    # random.sample picks POSITIONS: sampling range(len) draws the same entries, with the same
+    # consumption of the `random` stream, as sampling the sequence itself
+    train_memory = random.sample(range(len(rep_memory)), n) if on_device else random.sample(list(rep_memory), n)
     losses = []
     for epoch in range(n_epochs):
         for i in range(0, len(train_memory), BATCH_SIZE):
             batch = train_memory[i:i + BATCH_SIZE]
-            s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
-            pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
-            z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
+            if on_device:
+                s_batch, pi_batch, z_batch = rep_memory.batch(batch)
+            else:
+                s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
+                pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
+                z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
             p_batch, v_batch = Agent.model(s_batch)
             v_loss = (v_batch - z_batch).pow(2).mean()
             p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
@@ -256,6 +273,8 @@ def save_dataset(memory, n_iter, step_, directory='data', datetime_now=None):
     datetime_now = datetime_now or datetime.now().strftime('%y%m%d')
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, '{}_{}_{}_step_dataset.pickle'.format(datetime_now, n_iter, step_))
+    if not isinstance(memory, deque):                     # DeviceReplay: pickle what the reference pickles
+        memory = deque(list(memory), maxlen=memory.maxlen)
     with open(path, 'wb') as f:
         pickle.dump(memory, f, pickle.HIGHEST_PROTOCOL)
     return path
@@ -277,4 +296,9 @@ def load_data(model_path, dataset_path):
         start_iter = int(name.split('_')[1]) + 1
     if dataset_path:
         with open(dataset_path, 'rb') as f:
-            rep_memory = deque(pickle.load(f), maxlen=MEMORY_SIZE)
+            loaded = pickle.load(f)
+        if hasattr(rep_memory, "extend_augmented"):
+            rep_memory.clear()
+            rep_memory.extend(loaded)
+        else:
+            rep_memory = deque(loaded, maxlen=MEMORY_SIZE)

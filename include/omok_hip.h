@@ -148,6 +148,31 @@ int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launch
  * refers to, for a batch of `boards` positions. */
 int  ao_net_dominant_kernel(ao_net *n, int boards, char *name, int name_cap, double *flop_per_launch);
 
+/* ---- replay memory ---- replaces rep_memory = deque(maxlen=MEMORY_SIZE) (main.py:55), its
+ * rep_memory.extend(utils.augment_dataset(cur_memory, board_size)) (main.py:229-231,
+ * utils.py:226-239) and the mini-batch assembly of main.train (main.py:262-292). The ring lives in
+ * HBM; entries are in deque order (index 0 = oldest), the oldest are dropped when full. */
+typedef struct ao_replay ao_replay;
+int  ao_replay_create(int board, int inplanes, int64_t capacity, int device, ao_replay **out);
+void ao_replay_destroy(ao_replay *r);
+const char *ao_replay_last_error(const ao_replay *r);  /* r may be NULL: failed ao_replay_create */
+int64_t ao_replay_size(const ao_replay *r);            /* len(rep_memory)                        */
+int64_t ao_replay_capacity(const ao_replay *r);        /* rep_memory.maxlen                      */
+int  ao_replay_clear(ao_replay *r);
+/* Appends n samples given as host arrays: states float32 [n][C][B][B] (utils.get_state_pt planes,
+ * 0/1: exact in float32), pi float64 [n][A], z float32 [n]. augment != 0 appends the eight
+ * symmetries of every sample in the reference's order (rot90 k = 0..3, each followed by its
+ * left-right flip), computed on the device; augment == 0 appends the samples as they are. */
+int  ao_replay_extend(ao_replay *r, const float *states, const double *pi, const float *z, int64_t n,
+                      int augment, void *stream);
+/* Mini-batch for m deque indices (host int64; e.g. random.sample(range(len), m)): writes float32
+ * device buffers states [m][C][B][B], pi [m][A], z [m] -- the tensors main.train feeds the net. */
+int  ao_replay_gather(ao_replay *r, const int64_t *idx, int64_t m, float *dev_states, float *dev_pi,
+                      float *dev_z, void *stream);
+/* Reads entries [first, first+n) back to host float64 arrays (any may be NULL); this is what
+ * main.save_dataset pickles. */
+int  ao_replay_read(ao_replay *r, int64_t first, int64_t n, double *states, double *pi, double *z);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,140 @@
+"""-m gpu: device-resident replay memory (alpha_omok_amd.replay, csrc/replay.hip) against the
+reference's own data flow: deque(maxlen) + utils.augment_dataset (golden gv8 captured from the
+reference) + the mini-batches and losses of main.train."""
+import random
+from collections import deque
+
+import numpy as np
+import pytest
+
+import pvnet_weights
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(rs, n, B, C=5):
+    out = []
+    for _ in range(n):
+        s = (rs.rand(C, B, B) < 0.3).astype(np.float64)
+        pi = rs.dirichlet(np.ones(B * B))
+        out.append((s, pi, float(rs.choice([-1.0, 0.0, 1.0]))))
+    return out
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for (s0, p0, z0), (s1, p1, z1) in zip(a, b):
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(p0, p1)      # float64, bit for bit
+        assert z0 == z1
+
+
+def test_augment_on_device_matches_reference_golden():
+    """extend_augmented == the reference's augment_dataset output, entry by entry (gv8 fixture)."""
+    from alpha_omok_amd.replay import DeviceReplay
+    g = load_golden("gv8_augment")
+    for i, B in enumerate((3, 9)):
+        mem = DeviceReplay(B, 5, 64)
+        mem.extend_augmented([(g["s%d" % i], g["pi%d" % i], 1.0)])
+        assert len(mem) == 8
+        s, pi, z = mem.read(0, 8)
+        # the fixture's states are arbitrary float64 (every cell distinct, so a wrong permutation cannot
+        # pass); the memory holds planes as float32 -- exact for the engine's 0/1 planes
+        np.testing.assert_array_equal(s, g["as%d" % i].astype(np.float32).astype(np.float64))
+        np.testing.assert_array_equal(pi, g["api%d" % i])
+        assert (z == 1.0).all()
+        mem.close()
+
+
+@pytest.mark.parametrize("board,cap", [(9, 100), (15, 37), (3, 8), (9, 30000)])
+def test_ring_matches_deque_through_wraps(board, cap):
+    """Several extends, some larger than the capacity: contents and order == deque(maxlen).extend(augment(...))."""
+    from alpha_omok_amd import utils
+    from alpha_omok_amd.replay import DeviceReplay
+    rs = np.random.RandomState(board * 1000 + cap)
+    mem = DeviceReplay(board, 5, cap)
+    ref = deque(maxlen=cap)
+    assert mem.maxlen == cap and len(mem) == 0
+    for n in (3, 1, 7, 0, 11, 2):
+        smp = _samples(rs, n, board)
+        mem.extend_augmented(smp)
+        ref.extend(utils.augment_dataset(smp, board))
+        assert len(mem) == len(ref)
+        if cap <= 200:
+            _same(list(mem), list(ref))
+    _same(list(mem)[-40:], list(ref)[-40:])
+    _same([mem[0], mem[-1], mem[len(mem) // 2]], [ref[0], ref[-1], ref[len(ref) // 2]])
+    plain = _samples(rs, 5, board)
+    mem.extend(plain)
+    ref.extend(plain)
+    _same(list(mem)[-12:], list(ref)[-12:])
+    mem.clear()
+    assert len(mem) == 0
+    with pytest.raises(IndexError):
+        mem[0]
+    mem.close()
+
+
+def test_batches_match_host_assembly():
+    """batch(indices) == torch.tensor(np.stack(...)).float() of the same deque entries (main.py:283-290)."""
+    import torch
+    from alpha_omok_amd import utils
+    from alpha_omok_amd.replay import DeviceReplay, ReplayError
+    rs = np.random.RandomState(5)
+    smp = _samples(rs, 20, 9)
+    mem = DeviceReplay(9, 5, 120)
+    mem.extend_augmented(smp)
+    ref = deque(utils.augment_dataset(smp, 9), maxlen=120)
+    random.seed(3)
+    idx = random.sample(range(len(mem)), 64)
+    random.seed(3)
+    picked = random.sample(list(ref), 64)
+    s, pi, z = mem.batch(idx)
+    assert s.is_cuda and s.dtype == torch.float32 and tuple(s.shape) == (64, 5, 9, 9)
+    np.testing.assert_array_equal(s.cpu().numpy(), np.stack([b[0] for b in picked]).astype(np.float32))
+    np.testing.assert_array_equal(pi.cpu().numpy(), np.stack([b[1] for b in picked]).astype(np.float32))
+    np.testing.assert_array_equal(z.cpu().numpy(), np.array([b[2] for b in picked], np.float32))
+    with pytest.raises(ReplayError):
+        mem.batch([len(mem)])
+    with pytest.raises(ReplayError):
+        mem.extend([(np.zeros((5, 7, 7)), smp[0][1], 0.0)])         # wrong board
+    mem.close()
+
+
+def test_train_with_device_replay_equals_host_path(oracle):
+    """main.self_play + main.train with rep_memory in HBM: same memory contents, same mini-batches,
+    same losses as the host deque path under the same seeds."""
+    import torch
+    import alpha_omok_amd.main as main
+    from test_gpu_dropin import StubModel
+    from alpha_omok_amd.pvnet import PVNet
+    B = 9
+    results = []
+    for dev_replay in (False, True):
+        main.PRINT_SELFPLAY = False
+        main.configure(board_size=B, n_mcts=24, n_blocks=1, out_planes=32, seed=0, device_replay=dev_replay)
+        net = PVNet(1, 5, 32, B)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in pvnet_weights.make_state_dict(1, 5, 32, B, 2).items()})
+        main.Agent.model = StubModel(oracle, 1)
+        main.cur_memory.clear()
+        main.rep_memory.clear()
+        main.reset_iter(main.result, main.cur_memory)
+        main.self_play(3, seeds=[5, 6, 7])
+        mem = [(s.copy(), p.copy(), z) for s, p, z in main.rep_memory]
+        main.Agent.model = net.to(main.device)
+        main.optimizer = torch.optim.Adam(main.Agent.model.parameters(), lr=main.LR, weight_decay=main.L2, eps=1e-6)
+        random.seed(11)
+        torch.manual_seed(11)
+        n_keep = len(main.cur_memory)
+        while len(main.cur_memory) > 2:                # keeps the training pass short: 2 * 32 samples
+            main.cur_memory.pop()
+        losses = main.train(1, 0)
+        results.append((mem, losses, n_keep))
+    (mem_h, loss_h, n_h), (mem_d, loss_d, n_d) = results
+    assert n_h == n_d and len(mem_h) == 8 * n_h
+    _same(mem_h, mem_d)
+    assert len(loss_h) == len(loss_d) == 2
+    np.testing.assert_allclose(np.array(loss_h), np.array(loss_d), rtol=0, atol=2e-5)
+    main.configure(board_size=B, n_mcts=24, n_blocks=1, out_planes=32, seed=0)   # back to the host deque
+    assert isinstance(main.rep_memory, deque)
