@@ -201,8 +201,11 @@ def main():
         # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (they cannot
         # be collected inside this process); use the committed summary when it is for this workload
         traffic = None
+        traffic_src = None
         try:
-            with open(os.path.join(REPO, "profiles", "r1d_traffic.json")) as f:
+            import glob
+            traffic_src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]  # newest round
+            with open(traffic_src) as f:
                 tj = json.load(f)
             if (tj["kernel"].split("<")[0] == kname.split("<")[0] and G == 4096 and B == 9
                     and args.blocks == 4 and args.planes == 128):
@@ -241,7 +244,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1d_pmc.txt)",
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)"
+                                % (os.path.relpath(traffic_src, REPO) if traffic_src else "no profile"),
                 "flop_per_launch": f_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": conv_launches,

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Collects the rocprofv3 evidence bench.py's roofline refers to. Run ON THE GPU BOX:
+
+    python tools/profile_round.py r1e            # writes gpurun_out/profiles_r1e/*
+
+  <tag>_kernel_stats.txt   rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1`
+  <tag>_pmc.txt            FETCH_SIZE / WRITE_SIZE / SQ busy counters, one pass per counter set
+                           (separate runs with --kernel-trace only, as the pool requires)
+  <tag>_traffic.json       HBM bytes per launch of the dominant kernel (FETCH_SIZE x2 on gfx950)
+  <tag>_single_game_kernel_stats.txt   the latency path (one game, 400 sims/move)
+Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch)."""
+import glob, json, os, sqlite3, subprocess, sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1x"
+out = os.path.join(REPO, "gpurun_out", "profiles_" + tag)
+os.makedirs(out, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+summ = os.path.join(REPO, "tools", "rocpd_summary.py")
+
+
+def prof(name, extra, cmd):
+    d = os.path.join(out, "raw_" + name)
+    subprocess.run(["rocprofv3", "--kernel-trace"] + extra + ["-d", d, "-o", name, "--"] + cmd, cwd="/tmp", env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return dbs[0] if dbs else None
+
+
+bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game"]
+db = prof("stats", ["--stats"], bench + ["--steps", "2", "--warmup", "1"])
+with open(os.path.join(out, tag + "_kernel_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game\n")
+    f.write(subprocess.run([sys.executable, summ, "stats", db], capture_output=True, text=True).stdout)
+
+db1 = prof("single", ["--stats"], ["python", os.path.join(REPO, "tools", "time_single_game.py")])
+with open(os.path.join(out, tag + "_single_game_kernel_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python tools/time_single_game.py   (1 game, 9x9, 400 sims/move, 4-block net)\n")
+    f.write(subprocess.run([sys.executable, summ, "stats", db1], capture_output=True, text=True).stdout)
+
+short = bench + ["--steps", "1", "--warmup", "0", "--sims", "20"]
+sets = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+        "sq": ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES"]}
+vals = {}
+with open(os.path.join(out, tag + "_pmc.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 --sims 20 "
+            "--no-cpu-baseline --no-single-game (one pass per counter set)\n"
+            "# FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE under-counts wide coalesced reads "
+            "by 2x (MI355X_MICROARCH.md, HBM section)\n")
+    for name, ctrs in sets.items():
+        dbp = prof("pmc_" + name, ["--pmc"] + ctrs, short)
+        f.write("## pmc_%s\n" % name)
+        if not dbp:
+            f.write("(no output)\n")
+            continue
+        f.write(subprocess.run([sys.executable, summ, "pmc", dbp], capture_output=True, text=True).stdout)
+        c = sqlite3.connect(dbp)
+        for k, cn, a in c.execute("select kernel_name, counter_name, avg(value) from counters_collection "
+                                  "group by kernel_name, counter_name"):
+            vals[(k, cn)] = a
+
+dom = [k for (k, cn) in vals if "k_trunk16" in k]
+if dom:
+    k = dom[0]
+    fetch, write = vals.get((k, "FETCH_SIZE")), vals.get((k, "WRITE_SIZE"))
+    busy, mfma = vals.get((k, "SQ_BUSY_CYCLES")), vals.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"))
+    tj = {"kernel": "k_trunk16<9,9,1>",
+          "workload": "4096 boards, 4-block/128-ch PVNet, one launch = conv1 + 8 trunk convs + heads",
+          "fetch_size_kib": fetch, "write_size_kib": write, "fetch_correction": 2.0,
+          "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
+          "source": "profiles/%s_pmc.txt (rocprofv3 --pmc, separate passes, MI355X)" % tag}
+    # MFMA pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs; the kernel offers
+    # 1024 x (duration x 2.4 GHz) SIMD-cycles (duration from the --stats pass of the same build)
+    c = sqlite3.connect(db)
+    row = c.execute("select avg(end-start) from kernels where name like '%k_trunk16%'").fetchone()
+    if row and row[0] and mfma:
+        tj["avg_launch_ns"] = row[0]
+        tj["mfma_busy_fraction"] = mfma / (1024.0 * row[0] * 2.4)
+    tj["sq_valu_mfma_busy_cycles"] = mfma
+    tj["sq_busy_cycles"] = busy
+    tj["grbm_gui_active"] = vals.get((k, "GRBM_GUI_ACTIVE"))
+    with open(os.path.join(out, tag + "_traffic.json"), "w") as f:
+        json.dump(tj, f, indent=1)
+print("written:", sorted(os.listdir(out)))
