@@ -14,7 +14,7 @@ _SO = os.path.join(_HERE, "libomok_oracle.so")
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("omok_oracle.c", "omok_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("omok_oracle.c", "rollout_oracle.c", "omok_oracle.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
         return _SO
@@ -82,6 +82,9 @@ def lib():
     L.oo_self_play_game.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, P(C.c_int),
                                     P(C.c_double), P(C.c_double), P(C.c_int)]
     L.oo_self_play_game.restype = C.c_int
+    L.oo_rollout_search.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_int, P(_Rng),
+                                    P(C.c_double), P(C.c_double), P(C.c_int)]
+    L.oo_rollout_search.restype = C.c_int
     _lib = L
     return L
 
@@ -183,6 +186,19 @@ def stub_eval(planes, mode=0):
     val = C.c_float(0)
     lib().oo_stub_eval_planes(_fp(pl), B, Cn, mode, _fp(pol), C.byref(val))
     return pol, np.float32(val.value)
+
+
+def rollout_search(mode, board, num_mcts, root_id, rng, win_mark=0):
+    """PUCTAgent.get_pi (mode 0) / UCTAgent.get_pi (mode 1) on root_id with `rng` as np.random.
+    Returns (pi one-hot [A], stat [A] = child visits (PUCT) / child q (UCT, -inf elsewhere), action, nodes)."""
+    moves = np.ascontiguousarray(list(root_id)[1:], dtype=np.int32)
+    A = board * board
+    pi = np.zeros(A, np.float64)
+    stat = np.zeros(A, np.float64)
+    act = C.c_int(0)
+    nodes = lib().oo_rollout_search(mode, board, win_mark, num_mcts, _ip(moves) if len(moves) else None,
+                                    len(moves), rng._p, _dp(pi), _dp(stat), C.byref(act))
+    return pi, stat, act.value, nodes
 
 
 class Agent:

@@ -153,3 +153,22 @@ def test_self_play_game_matches_stepwise(oracle):
         assert w == win
         np.testing.assert_array_equal(pis, g["c%d_pi" % ci])
         np.testing.assert_array_equal(vis, g["c%d_visit" % ci])
+
+
+def test_rollout_agents_match_reference(oracle):
+    """PUCTAgent / UCTAgent.get_pi (agents.py:263-614) restated in oracle/rollout_oracle.c: one-hot pi,
+    root-child visits (PUCT) / q (UCT), chosen move and np.random stream position after every call,
+    for consecutive calls under one np.random.seed (gv11 captured from the reference)."""
+    g = load_golden("gv11_rollout_agents")
+    for ci in range(int(g["ncases"])):
+        mode, B, S, seed, nrec = g["c%d_cfg" % ci].tolist()
+        root = (0,) + tuple(int(a) for a in g["c%d_start" % ci])
+        rng = oracle.Rng(seed)
+        assert nrec >= 1
+        for t in range(nrec):
+            pi, stat, action, _ = oracle.rollout_search(mode, B, S, root, rng)
+            np.testing.assert_array_equal(pi, g["c%d_pi" % ci][t], err_msg="case %d call %d" % (ci, t))
+            np.testing.assert_array_equal(stat, g["c%d_stat" % ci][t], err_msg="case %d call %d" % (ci, t))
+            assert action == int(g["c%d_action" % ci][t])
+            assert rng.pos == int(g["c%d_pos" % ci][t])
+            root = root + (action,)

@@ -11,7 +11,8 @@ the .npz files.
 Fixture ids follow SURVEY.md section 8(c): GV1 check_win, GV2 legal_actions order, GV3 state
 planes / board / turn, GV4 numpy RNG stream, GV5 tree parity with the exact-arithmetic stub
 evaluator, GV6 tree parity with the real PVNet (evaluations recorded for replay), GV7 PVNet
-forward, GV8 augment_dataset order, GV9 main.self_play memory order + z, GV10 one train step.
+forward, GV8 augment_dataset order, GV9 main.self_play memory order + z, GV10 one train step,
+GV11 rollout agents (PUCTAgent / UCTAgent.get_pi: one-hot, child visits / q, stream position).
 """
 import os
 import sys
@@ -435,7 +436,52 @@ def gv10():
     save("gv10_train_step", **out)
 
 
-ALL = dict(gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
+def gv11():
+    """Rollout agents: PUCTAgent / UCTAgent.get_pi (agents.py:263-614) under np.random.seed, several
+    consecutive calls per agent object (each call is a fresh search; stale dict entries must not matter)."""
+    import contextlib
+    import io
+    cases = [  # (mode, B, num_mcts, seed, start moves, plies)
+        (0, 3, 200, 1, (), 4), (1, 3, 200, 2, (), 4), (0, 3, 60, 3, (4, 0, 8), 3), (1, 3, 60, 4, (4, 0, 8, 2), 3),
+        (0, 9, 60, 5, (), 3), (1, 9, 60, 6, (), 3), (0, 9, 40, 7, (40, 41, 31, 32, 22, 23, 13), 3),
+        (1, 9, 40, 8, (40, 41, 31, 32, 22, 23, 13), 3), (0, 15, 16, 9, (112, 113), 2), (1, 15, 16, 10, (112, 113), 2),
+    ]
+    # a crowded, still undecided 9x9 position (short playouts, many terminal leaves, draws possible)
+    for sd in range(1000):
+        dense = tuple(np.random.RandomState(sd).permutation(81)[:66].tolist())
+        if ref_utils.check_win(ref_utils.get_board((0,) + dense, 9), 5) == 0:
+            break
+    cases += [(0, 9, 30, 11, dense, 3), (1, 9, 30, 12, dense, 3)]
+    out = dict(ncases=np.array(len(cases)))
+    for ci, (mode, B, S, seed, start, plies) in enumerate(cases):
+        agent = (ref_agents.PUCTAgent if mode == 0 else ref_agents.UCTAgent)(B, S)
+        np.random.seed(seed)
+        root = (0,) + tuple(int(a) for a in start)
+        recs = dict(pi=[], stat=[], action=[], pos=[])
+        nrec = 0
+        for t in range(plies):
+            board = ref_utils.get_board(root, B)
+            if ref_utils.check_win(board, agent.win_mark) != 0:
+                break
+            with contextlib.redirect_stdout(io.StringIO()):
+                pi = agent.get_pi(root, board, ref_utils.get_turn(root), 0)
+            stat = np.zeros(B * B) if mode == 0 else np.full(B * B, -np.inf)
+            for a in agent.tree[root]['child']:
+                stat[a] = agent.tree[root + (a,)]['n' if mode == 0 else 'q']
+            recs["pi"].append(pi.copy())
+            recs["stat"].append(stat)
+            recs["action"].append(int(np.argmax(pi)))
+            recs["pos"].append(int(np.random.get_state()[2]))
+            root = root + (int(np.argmax(pi)),)
+            nrec += 1
+        out["c%d_cfg" % ci] = np.array([mode, B, S, seed, nrec], np.int64)
+        out["c%d_start" % ci] = np.array(start, np.int64)
+        for k, v in recs.items():
+            out["c%d_%s" % (ci, k)] = np.array(v)
+    save("gv11_rollout_agents", **out)
+
+
+ALL = dict(gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
            gv10=gv10)
 
 if __name__ == "__main__":
