@@ -19,6 +19,11 @@ class AoConfig(C.Structure):
                 ("alpha", C.c_double)]
 
 
+class AoRolloutConfig(C.Structure):
+    _fields_ = [("board", C.c_int32), ("win_mark", C.c_int32), ("sims", C.c_int32), ("games", C.c_int32),
+                ("mode", C.c_int32), ("device", C.c_int32), ("c_puct", C.c_double)]
+
+
 _P = C.POINTER
 _vp = C.c_void_p
 _i32p, _u32p, _u8p, _i8p, _f64p, _i64p = (_P(C.c_int32), _P(C.c_uint32), _P(C.c_uint8),
@@ -69,6 +74,13 @@ SYMBOLS = {
     "ao_replay_extend": (C.c_int, [_vp, _P(C.c_float), _f64p, _P(C.c_float), C.c_int64, C.c_int, _vp]),
     "ao_replay_gather": (C.c_int, [_vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
     "ao_replay_read": (C.c_int, [_vp, C.c_int64, C.c_int64, _f64p, _f64p, _f64p]),
+    "ao_rollout_create": (C.c_int, [_P(AoRolloutConfig), _P(_vp)]),
+    "ao_rollout_destroy": (None, [_vp]),
+    "ao_rollout_last_error": (C.c_char_p, [_vp]),
+    "ao_rollout_seed": (C.c_int, [_vp, C.c_int, C.c_uint32]),
+    "ao_rollout_get_rng_state": (C.c_int, [_vp, C.c_int, _u32p, _i32p, _i32p, _f64p]),
+    "ao_rollout_set_rng_state": (C.c_int, [_vp, C.c_int, _u32p, C.c_int32, C.c_int32, C.c_double]),
+    "ao_rollout_search": (C.c_int, [_vp, _i32p, _i32p, _u8p, _f64p, _f64p, _i32p]),
 }
 
 _lib = None

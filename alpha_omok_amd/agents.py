@@ -1,4 +1,5 @@
-"""Drop-in `agents.ZeroAgent` backed by the HIP engine (reference: agents.py:16-260).
+"""Drop-in `agents.ZeroAgent` (reference: agents.py:16-260) and the net-free rollout agents
+`PUCTAgent` / `UCTAgent` (agents.py:263-614), all backed by the HIP engine.
 
 Same constructor, attributes and methods as the reference class; the per-simulation Python loop
 is replaced by the batched tree kernels with G = 1. The evaluator is `self.model`, assigned after
@@ -139,3 +140,64 @@ class ZeroAgent(Agent):
                     self.model.eval()
                 p, v = self.model(x.to(Evaluator._model_device(self.model)))
         return p.detach().cpu().numpy()[0], v.detach().cpu().numpy()[0]
+
+
+class _RolloutAgent(Agent):
+    """Shared body of PUCTAgent / UCTAgent (agents.py:263-614): every get_pi is a fresh search of
+    num_mcts + 1 simulations with random playouts, run as ONE kernel on the device with the
+    process-global np.random state (moved in and out as ZeroAgent does)."""
+    _MODE = 0
+
+    def __init__(self, board_size, num_mcts, device=0):
+        super(_RolloutAgent, self).__init__(board_size)
+        self.board_size = board_size
+        self.num_mcts = num_mcts
+        self.win_mark = 3 if board_size == 3 else 5
+        self.root_id = None
+        self.board = None
+        self.turn = None
+        self.is_real_root = True
+        self._device = device
+        self._engine = None
+        self.tree = {}     # the reference keeps its dict across calls but never reads old entries
+
+    def reset(self):
+        self.is_real_root = True
+        self.root_id = None
+        self.board = None
+        self.turn = None
+        self.tree.clear()
+
+    def get_pi(self, root_id, board, turn, tau):
+        from . import utils
+        from .rollout import RolloutEngine
+        if turn != utils.get_turn(root_id):
+            raise ValueError("turn does not match root_id")
+        if self._engine is None:
+            self._engine = RolloutEngine(self.board_size, self.num_mcts, self._MODE, games=1, device=self._device)
+        self.root_id, self.board, self.turn = root_id, board, turn
+        start = time.time()
+        st = np.random.get_state()
+        self._engine.set_rng_state(0, st[1], st[2], st[3], st[4])
+        pi, stat, _ = self._engine.search([root_id])
+        mt, pos, hg, gs = self._engine.get_rng_state(0)
+        np.random.set_state(('MT19937', mt, pos, hg, gs))
+        if self._MODE == 0:
+            self.visit = stat[0].copy()
+        self.tree = {root_id: {'child': [a for a in range(self.board_size ** 2) if a not in root_id[1:]]}}
+        if PRINT_MCTS:
+            print("{} simulations end ({:0.0f}s)".format(self.num_mcts, time.time() - start))
+        return pi[0].copy()
+
+    def del_parents(self, root_id):
+        self.tree = {k: v for k, v in self.tree.items() if len(k) >= len(root_id)}
+
+
+class PUCTAgent(_RolloutAgent):
+    """agents.py:263-441: PUCT over uniform priors, value from one random playout per expansion."""
+    _MODE = 0
+
+
+class UCTAgent(_RolloutAgent):
+    """agents.py:443-614: UCB1 (unvisited children first), value from one random playout per expansion."""
+    _MODE = 1

@@ -173,6 +173,34 @@ int  ao_replay_gather(ao_replay *r, const int64_t *idx, int64_t m, float *dev_st
  * main.save_dataset pickles. */
 int  ao_replay_read(ao_replay *r, int64_t first, int64_t n, double *states, double *pi, double *z);
 
+/* ---- rollout agents ---- replace PUCTAgent.get_pi (agents.py:263-441) and UCTAgent.get_pi
+ * (agents.py:443-614): net-free searches with random playouts. One handle owns G independent
+ * games, each with its own numpy-legacy MT19937 stream; a search runs entirely in one kernel. */
+typedef struct ao_rollout ao_rollout;
+typedef struct ao_rollout_config {
+    int32_t board;     /* board edge 3..15                                                     */
+    int32_t win_mark;  /* 0 = reference rule: 3 if board == 3 else 5 (agents.py:270)           */
+    int32_t sims;      /* num_mcts; every get_pi runs num_mcts + 1 simulations (agents.py:318) */
+    int32_t games;     /* G                                                                    */
+    int32_t mode;      /* 0 = PUCTAgent, 1 = UCTAgent                                          */
+    int32_t device;
+    double  c_puct;    /* 0 = 5 (agents.py:271); PUCT only                                     */
+} ao_rollout_config;
+int  ao_rollout_create(const ao_rollout_config *cfg, ao_rollout **out);
+void ao_rollout_destroy(ao_rollout *r);
+const char *ao_rollout_last_error(const ao_rollout *r); /* r may be NULL: failed create          */
+int  ao_rollout_seed(ao_rollout *r, int game, uint32_t seed);            /* np.random.seed(seed) */
+int  ao_rollout_get_rng_state(ao_rollout *r, int game, uint32_t *mt624, int32_t *pos,
+                              int32_t *has_gauss, double *gauss);
+int  ao_rollout_set_rng_state(ao_rollout *r, int game, const uint32_t *mt624, int32_t pos,
+                              int32_t has_gauss, double gauss);
+/* get_pi(root_id, board, turn, tau) for every active game: moves [G][A] (row g = root_id[1:] of
+ * game g, first nmoves[g] entries used; board and turn follow from the id). Host outputs
+ * (any may be NULL): pi float64 [G][A] one-hot; stat float64 [G][A] = visit counts of the root's
+ * children (PUCT, 0 elsewhere) or their q (UCT, -inf elsewhere); action int32 [G]. */
+int  ao_rollout_search(ao_rollout *r, const int32_t *moves, const int32_t *nmoves,
+                       const uint8_t *active, double *pi, double *stat, int32_t *action);
+
 #ifdef __cplusplus
 }
 #endif
