@@ -85,6 +85,12 @@ def lib():
     L.oo_rollout_search.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int), C.c_int, P(_Rng),
                                     P(C.c_double), P(C.c_double), P(C.c_int)]
     L.oo_rollout_search.restype = C.c_int
+    L.oo_pyrandom_seed.argtypes = [P(_Rng), C.c_uint32]
+    L.oo_pyrandom_below.argtypes = [P(_Rng), C.c_int]
+    L.oo_pyrandom_below.restype = C.c_int
+    L.oo_ttt_search.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int8), C.c_int, P(_Rng), P(C.c_double),
+                                P(C.c_double)]
+    L.oo_ttt_search.restype = C.c_int
     _lib = L
     return L
 
@@ -199,6 +205,26 @@ def rollout_search(mode, board, num_mcts, root_id, rng, win_mark=0):
     nodes = lib().oo_rollout_search(mode, board, win_mark, num_mcts, _ip(moves) if len(moves) else None,
                                     len(moves), rng._p, _dp(pi), _dp(stat), C.byref(act))
     return pi, stat, act.value, nodes
+
+
+class PyRandom(Rng):
+    """Python's `random` module stream (random.seed(int) / _randbelow) on the same MT19937 core."""
+
+    def seed(self, s):
+        lib().oo_pyrandom_seed(self._p, s)
+
+    def randbelow(self, n):
+        return lib().oo_pyrandom_below(self._p, n)
+
+
+def ttt_search(game_board, turn, num_mcts, rng, win_mark=3):
+    """The per-move UCT search of 1_tictactoe_MCTS/mcts_vs.py:153-183. Returns (max_action, q [A], n [A])."""
+    b = np.ascontiguousarray(np.asarray(game_board), dtype=np.int8)
+    B = b.shape[0]
+    q = np.zeros(B * B, np.float64)
+    n = np.zeros(B * B, np.float64)
+    a = lib().oo_ttt_search(B, win_mark, num_mcts, b.ctypes.data_as(C.POINTER(C.c_int8)), int(turn), rng._p, _dp(q), _dp(n))
+    return a, q, n
 
 
 class Agent:

@@ -188,3 +188,186 @@ int oo_rollout_search(int mode, int board, int win_mark, int num_mcts, const int
     free(t.nodes); free(root_board); free(b); free(sim); free(qu); free(acts);
     return used;
 }
+
+/* =================================================================================================
+ * 1_tictactoe_MCTS/mcts_vs.py (BASELINE configs[0]): the UCT search its __main__ runs per move
+ *   MCTS.selection  mcts_vs.py:15-46    q + u, u = 5 * sqrt(2 * ln(N_parent) / n), an unvisited child
+ *                                        uses n = 0.0001; strict '>' from -100: the FIRST maximum wins
+ *   MCTS.expansion  mcts_vs.py:48-93    only the root or a node with n > 10 is expanded; all children
+ *                                        are created, ONE is picked by random.sample(childs, 1)
+ *   MCTS.simulation mcts_vs.py:95-111   random.choice(valid_actions) until check_win != 0
+ *   MCTS.backup     mcts_vs.py:113-131  value = 0.8 (draw) / +1 (root player wins) / -1, the SAME value
+ *                                        added at every node of the path (no sign alternation)
+ *   driver          mcts_vs.py:153-183  num_mcts iterations, action = first arg-max of the root
+ *                                        children's q
+ * Randomness is Python's `random` module: MT19937 seeded by init_by_array, getrandbits(k) =
+ * genrand_uint32() >> (32 - k), _randbelow(n) = rejection on k = n.bit_length() bits.
+ * ================================================================================================= */
+void oo_pyrandom_seed(oo_rng *r, uint32_t seed)
+{
+    /* random.seed(int < 2**32) -> init_by_array([seed]) (CPython _randommodule.c) */
+    uint32_t *mt = r->mt;
+    mt[0] = 19650218U;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int i = 1, j = 0;
+    for (int k = 624; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525U)) + seed + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (j >= 1) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000U;
+    r->pos = 624;
+    r->has_gauss = 0;
+    r->gauss = 0.0;
+}
+
+int oo_pyrandom_below(oo_rng *r, int n)
+{
+    /* Random._randbelow_with_getrandbits (random.py): k = n.bit_length() */
+    int k = 0;
+    while ((n >> k) != 0) k++;
+    uint32_t v;
+    do { v = oo_rng_next32(r) >> (32 - k); } while ((int)v >= n);
+    return (int)v;
+}
+
+typedef struct tnode {
+    int parent, action, player, first_kid, nkids, n;
+    double w, q;
+} tnode;
+
+/* utils.check_win of 1_tictactoe_MCTS (rows, columns, diagonals, anti-diagonals; draw last) */
+static int ttt_check_win(const int8_t *b, int n, int k)
+{
+    int marks = 0;
+    for (int i = 0; i < n * n; i++) marks += (b[i] != 0);
+    for (int row = 0; row < n; row++)
+        for (int col = 0; col + k <= n; col++) {
+            int s = 0;
+            for (int i = 0; i < k; i++) s += b[row * n + col + i];
+            if (s == k) return 1;
+            if (s == -k) return 2;
+        }
+    for (int row = 0; row + k <= n; row++)
+        for (int col = 0; col < n; col++) {
+            int s = 0;
+            for (int i = 0; i < k; i++) s += b[(row + i) * n + col];
+            if (s == k) return 1;
+            if (s == -k) return 2;
+        }
+    for (int row = 0; row + k <= n; row++)
+        for (int col = 0; col + k <= n; col++) {
+            int s = 0;
+            for (int i = 0; i < k; i++) s += b[(row + i) * n + col + i];
+            if (s == k) return 1;
+            if (s == -k) return 2;
+        }
+    for (int row = k - 1; row < n; row++)
+        for (int col = 0; col + k <= n; col++) {
+            int s = 0;
+            for (int i = 0; i < k; i++) s += b[(row - i) * n + col + i];
+            if (s == k) return 1;
+            if (s == -k) return 2;
+        }
+    if (marks == n * n) return 3;
+    return 0;
+}
+
+int oo_ttt_search(int board, int win_mark, int num_mcts, const int8_t *game_board, int turn, oo_rng *rng,
+                  double *q_out, double *n_out)
+{
+    const int A = board * board;
+    tnode *t = NULL;
+    int used = 0, cap = 0;
+#define TT_NEW(par, act, pl) do { if (used == cap) { cap = cap ? cap * 2 : 1024; t = (tnode *)realloc(t, sizeof(tnode) * (size_t)cap); } \
+        t[used].parent = (par); t[used].action = (act); t[used].player = (pl); t[used].first_kid = -1; t[used].nkids = 0; \
+        t[used].n = 0; t[used].w = 0; t[used].q = 0; used++; } while (0)
+    TT_NEW(-1, -1, turn);
+    int8_t *b = (int8_t *)malloc((size_t)A);
+    int *acts = (int *)malloc(sizeof(int) * (size_t)A);
+    int *path = (int *)malloc(sizeof(int) * (size_t)(A + 2));
+
+    for (int it = 0; it < num_mcts; it++) {
+        /* selection */
+        int node = 0;
+        while (t[node].nkids != 0) {
+            double max_value = -100;
+            const int leaf = node;
+            for (int i = 0; i < t[leaf].nkids; i++) {
+                const tnode *c = &t[t[leaf].first_kid + i];
+                const double total_n = (double)t[c->parent].n;
+                double q, u;
+                if (c->n == 0) {
+                    q = c->w / 0.0001;
+                    double x = 2 * log(total_n);
+                    x = x / 0.0001;
+                    u = 5 * sqrt(x);
+                } else {
+                    q = c->w / c->n;
+                    double x = 2 * log(total_n);
+                    x = x / c->n;
+                    u = 5 * sqrt(x);
+                }
+                if (q + u > max_value) { max_value = q + u; node = t[leaf].first_kid + i; }
+            }
+            if (node == leaf) break;   /* (the reference would spin forever; unreachable for q >= -1) */
+        }
+        /* state of the leaf: replay the path from the root */
+        memcpy(b, game_board, (size_t)A);
+        int plen = 0;
+        for (int k = node; t[k].parent >= 0; k = t[k].parent) path[plen++] = k;
+        for (int i = plen - 1; i >= 0; i--) b[t[path[i]].action] = (int8_t)(t[t[path[i]].parent].player == 0 ? 1 : -1);
+        /* expansion */
+        int child = node;
+        const int is_terminal = ttt_check_win(b, board, win_mark);
+        if (is_terminal == 0 && (node == 0 || t[node].n > 10)) {
+            int na = 0;
+            for (int c = 0; c < A; c++) if (b[c] == 0) acts[na++] = c;
+            const int first = used;
+            for (int i = 0; i < na; i++) TT_NEW(node, acts[i], t[node].player == 0 ? 1 : 0);
+            t[node].first_kid = first;
+            t[node].nkids = na;
+            child = first + oo_pyrandom_below(rng, na);   /* random.sample(childs, 1)[0] */
+            b[t[child].action] = (int8_t)(t[node].player == 0 ? 1 : -1);
+        }
+        /* simulation */
+        int player = t[child].player, win;
+        for (;;) {
+            win = ttt_check_win(b, board, win_mark);
+            if (win != 0) break;
+            int na = 0;
+            for (int c = 0; c < A; c++) if (b[c] == 0) acts[na++] = c;
+            const int a = acts[oo_pyrandom_below(rng, na)];   /* random.choice(actions) */
+            if (player == 0) { player = 1; b[a] = 1; } else { player = 0; b[a] = -1; }
+        }
+        /* backup */
+        double value;
+        if (win == 3) value = 0.8;
+        else if (win - 1 == t[0].player) value = 1;
+        else value = -1;
+        for (int k = child;; k = t[k].parent) {
+            t[k].n += 1;
+            t[k].w += value;
+            t[k].q = t[k].w / t[k].n;
+            if (t[k].parent == 0) { t[0].n += 1; break; }
+            if (t[k].parent < 0) break;   /* child is the root itself: the reference raises here */
+        }
+    }
+    for (int a = 0; a < A; a++) { q_out[a] = -INFINITY; n_out[a] = 0; }
+    int best = -1;
+    double bq = 0;
+    for (int i = 0; i < t[0].nkids; i++) {
+        const tnode *c = &t[t[0].first_kid + i];
+        q_out[c->action] = c->q;
+        n_out[c->action] = c->n;
+        if (best < 0 || c->q > bq) { best = c->action; bq = c->q; }   /* max(q_list, key=q_list.get): first maximum */
+    }
+    free(t); free(b); free(acts); free(path);
+    return best;
+}

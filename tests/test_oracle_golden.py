@@ -172,3 +172,19 @@ def test_rollout_agents_match_reference(oracle):
             assert action == int(g["c%d_action" % ci][t])
             assert rng.pos == int(g["c%d_pos" % ci][t])
             root = root + (action,)
+
+
+def test_tictactoe_uct_matches_reference(oracle):
+    """BASELINE configs[0]: the per-move UCT search of 1_tictactoe_MCTS/mcts_vs.py (selection / expansion /
+    simulation / backup, lines 15-131, driven as its __main__ does) under random.seed: q and n of the root
+    children, max_action and the complete final state of Python's `random` stream (gv12)."""
+    g = load_golden("gv12_tictactoe_uct")
+    for ci in range(int(g["ncases"])):
+        turn, num_mcts, seed, max_action, pos = g["c%d_cfg" % ci].tolist()
+        rng = oracle.PyRandom(seed)
+        a, q, n = oracle.ttt_search(g["c%d_board" % ci], turn, num_mcts, rng)
+        assert a == max_action, "case %d" % ci
+        np.testing.assert_array_equal(q, g["c%d_q" % ci], err_msg="case %d" % ci)
+        np.testing.assert_array_equal(n, g["c%d_n" % ci], err_msg="case %d" % ci)
+        assert rng.pos == pos
+        np.testing.assert_array_equal(rng.state_words(), g["c%d_mt" % ci])

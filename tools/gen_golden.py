@@ -12,7 +12,8 @@ Fixture ids follow SURVEY.md section 8(c): GV1 check_win, GV2 legal_actions orde
 planes / board / turn, GV4 numpy RNG stream, GV5 tree parity with the exact-arithmetic stub
 evaluator, GV6 tree parity with the real PVNet (evaluations recorded for replay), GV7 PVNet
 forward, GV8 augment_dataset order, GV9 main.self_play memory order + z, GV10 one train step,
-GV11 rollout agents (PUCTAgent / UCTAgent.get_pi: one-hot, child visits / q, stream position).
+GV11 rollout agents (PUCTAgent / UCTAgent.get_pi: one-hot, child visits / q, stream position),
+GV12 the 3x3 UCT search of 1_tictactoe_MCTS/mcts_vs.py under Python's `random` (BASELINE configs[0]).
 """
 import os
 import sys
@@ -481,7 +482,60 @@ def gv11():
     save("gv11_rollout_agents", **out)
 
 
-ALL = dict(gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
+def gv12():
+    """BASELINE configs[0]: the UCT search of 1_tictactoe_MCTS/mcts_vs.py (its __main__ loop, lines 153-183)
+    driven through the reference's MCTS methods under random.seed; records q / n of the root children,
+    max_action and the final `random` state."""
+    import importlib.util
+    import random
+    ttt = "/root/reference/1_tictactoe_MCTS"
+    saved = list(sys.path)
+    sys.path.insert(0, ttt)
+    for m in ("utils", "env"):
+        sys.modules.pop(m, None)
+    spec = importlib.util.spec_from_file_location("ref_mcts_vs", os.path.join(ttt, "mcts_vs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)          # __main__ guard: only the MCTS class is defined
+    sys.path[:] = saved
+    for m in ("utils", "env"):
+        sys.modules.pop(m, None)
+    agent = mod.MCTS(3)
+    boards = [np.zeros((3, 3)),
+              np.array([[1., 0, 0], [0, -1, 0], [0, 0, 0]]),
+              np.array([[1., -1, 1], [0, -1, 0], [0, 1, 0]]),
+              np.array([[1., -1, 0], [0, 1, 0], [0, 0, -1]]),
+              np.array([[1., -1, 1], [-1, 1, 1], [0, 0, -1]]) * 1.0,
+              np.array([[0., 0, 0], [0, 1, 0], [0, 0, 0]])]
+    cases = []
+    for bi, gb in enumerate(boards):
+        turn = 0 if np.count_nonzero(gb) % 2 == 0 else 1
+        for num_mcts, seed in ((200, 10 + bi), (1500, 20 + bi), (37, 30 + bi)):
+            random.seed(seed)
+            tree = {(0,): {'state': gb.copy(), 'player': turn, 'child': [], 'parent': None, 'n': 0, 'w': None, 'q': None}}
+            for _ in range(num_mcts):
+                leaf_id = agent.selection(tree)
+                tree, child_id = agent.expansion(tree, leaf_id)
+                sim_result = agent.simulation(tree, child_id)
+                tree = agent.backup(tree, child_id, sim_result)
+            q = np.full(9, -np.inf)
+            n = np.zeros(9)
+            q_list = {}
+            for i in tree[(0,)]['child']:
+                q[i] = tree[(0, i)]['q']
+                n[i] = tree[(0, i)]['n']
+                q_list[(0, i)] = tree[(0, i)]['q']
+            max_action = max(q_list, key=q_list.get)[1]
+            st = random.getstate()
+            cases.append(dict(board=gb.astype(np.int8), cfg=np.array([turn, num_mcts, seed, max_action, st[1][624]], np.int64),
+                              q=q, n=n, mt=np.array(st[1][:624], np.uint32)))
+    out = dict(ncases=np.array(len(cases)))
+    for ci, c in enumerate(cases):
+        for k, v in c.items():
+            out["c%d_%s" % (ci, k)] = v
+    save("gv12_tictactoe_uct", **out)
+
+
+ALL = dict(gv12=gv12, gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
            gv10=gv10)
 
 if __name__ == "__main__":
