@@ -24,6 +24,11 @@ class AoRolloutConfig(C.Structure):
                 ("mode", C.c_int32), ("device", C.c_int32), ("c_puct", C.c_double)]
 
 
+class AoTttConfig(C.Structure):
+    _fields_ = [("board", C.c_int32), ("win_mark", C.c_int32), ("sims", C.c_int32), ("games", C.c_int32),
+                ("device", C.c_int32)]
+
+
 _P = C.POINTER
 _vp = C.c_void_p
 _i32p, _u32p, _u8p, _i8p, _f64p, _i64p = (_P(C.c_int32), _P(C.c_uint32), _P(C.c_uint8),
@@ -81,6 +86,13 @@ SYMBOLS = {
     "ao_rollout_get_rng_state": (C.c_int, [_vp, C.c_int, _u32p, _i32p, _i32p, _f64p]),
     "ao_rollout_set_rng_state": (C.c_int, [_vp, C.c_int, _u32p, C.c_int32, C.c_int32, C.c_double]),
     "ao_rollout_search": (C.c_int, [_vp, _i32p, _i32p, _u8p, _f64p, _f64p, _i32p]),
+    "ao_ttt_create": (C.c_int, [_P(AoTttConfig), _P(_vp)]),
+    "ao_ttt_destroy": (None, [_vp]),
+    "ao_ttt_last_error": (C.c_char_p, [_vp]),
+    "ao_ttt_seed": (C.c_int, [_vp, C.c_int, C.c_uint32]),
+    "ao_ttt_get_rng_state": (C.c_int, [_vp, C.c_int, _u32p, _i32p]),
+    "ao_ttt_set_rng_state": (C.c_int, [_vp, C.c_int, _u32p, C.c_int32]),
+    "ao_ttt_search": (C.c_int, [_vp, _i8p, _i32p, _u8p, _f64p, _f64p, _i32p]),
 }
 
 _lib = None

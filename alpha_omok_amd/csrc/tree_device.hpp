@@ -88,8 +88,8 @@ __device__ __forceinline__ void pos_clear(Pos& s) {
 // 0 playing, 1 black, 2 white, 3 draw (utils.py:30-59). Equivalent to the reference's window
 // scan because the parent position was not terminal: only a line through the new stone can be
 // new, and any run >= win_mark contains a window of exactly win_mark (overlines count).
-__device__ __forceinline__ int win_after_move(const Pos& s, int cell, int B, int win_mark) {
-    const int mover = (s.ply - 1) & 1;
+// `mover` = colour index (0 / 1) of the stone just placed, `stones` = stones on the board now.
+__device__ __forceinline__ int win_after_move_by(const Pos& s, int cell, int B, int win_mark, int mover, int stones) {
     const int lane = lane_id();
     // lane l < 32: direction l>>3, offset index l&7 -> offsets -4..-1, +1..+4
     const int dir = (lane >> 3) & 3;
@@ -113,8 +113,12 @@ __device__ __forceinline__ int win_after_move(const Pos& s, int cell, int B, int
         won = won || (run >= win_mark);
     }
     if (won) return mover + 1;
-    if (s.ply == B * B) return 3;
+    if (stones == B * B) return 3;
     return 0;
+}
+
+__device__ __forceinline__ int win_after_move(const Pos& s, int cell, int B, int win_mark) {
+    return win_after_move_by(s, cell, B, win_mark, (s.ply - 1) & 1, s.ply);
 }
 
 // ----------------------------------------------------------------------------------------------

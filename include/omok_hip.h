@@ -201,6 +201,29 @@ int  ao_rollout_set_rng_state(ao_rollout *r, int game, const uint32_t *mt624, in
 int  ao_rollout_search(ao_rollout *r, const int32_t *moves, const int32_t *nmoves,
                        const uint8_t *active, double *pi, double *stat, int32_t *action);
 
+/* ---- 3x3 UCT of 1_tictactoe_MCTS ---- replaces the per-move search loop of mcts_vs.py:153-183
+ * (MCTS.selection / expansion / simulation / backup, mcts_vs.py:15-131; BASELINE configs[0]).
+ * Randomness is Python's `random` module stream (MT19937 words + index, random.getstate()[1]). */
+typedef struct ao_ttt ao_ttt;
+typedef struct ao_ttt_config {
+    int32_t board;     /* state_size (env.py: 3); any 3..15                                    */
+    int32_t win_mark;  /* 0 = 3 on a 3x3 board, else 5                                         */
+    int32_t sims;      /* num_mcts (mcts_vs.py:144: 1500)                                      */
+    int32_t games;     /* G independent searches per call                                      */
+    int32_t device;
+} ao_ttt_config;
+int  ao_ttt_create(const ao_ttt_config *cfg, ao_ttt **out);
+void ao_ttt_destroy(ao_ttt *r);
+const char *ao_ttt_last_error(const ao_ttt *r);   /* r may be NULL: failed create */
+int  ao_ttt_seed(ao_ttt *r, int game, uint32_t seed);                       /* random.seed(seed)     */
+int  ao_ttt_get_rng_state(ao_ttt *r, int game, uint32_t *mt624, int32_t *pos);   /* random.getstate() */
+int  ao_ttt_set_rng_state(ao_ttt *r, int game, const uint32_t *mt624, int32_t pos);
+/* boards int8 [G][A] row-major (+1 = O / first player, -1 = X), turns int32 [G] (0 = O to move).
+ * Host outputs (any may be NULL): q float64 [G][A] of the root's children (-inf elsewhere), n float64
+ * [G][A] their visit counts, action int32 [G] = max_action (first maximum of q). */
+int  ao_ttt_search(ao_ttt *r, const int8_t *boards, const int32_t *turns, const uint8_t *active,
+                   double *q, double *n, int32_t *action);
+
 #ifdef __cplusplus
 }
 #endif

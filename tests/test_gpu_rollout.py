@@ -81,3 +81,56 @@ def test_rollout_errors():
     pi, stat, act = eng.search([(0, 40)])
     assert pi.sum() == 1 and stat[0, 40] == 0 and stat.sum() == 10
     eng.close()
+
+
+def test_tictactoe_uct_dropin_matches_reference_golden():
+    """BASELINE configs[0]: random.seed(s); uct_search(board, turn, num_mcts) == the reference's per-move search
+    (mcts_vs.py:153-183): max_action, q of every root child, and the `random` state it leaves behind (gv12)."""
+    import random
+    from alpha_omok_amd.tictactoe import uct_search
+    g = load_golden("gv12_tictactoe_uct")
+    for ci in range(int(g["ncases"])):
+        turn, num_mcts, seed, max_action, pos = g["c%d_cfg" % ci].tolist()
+        random.seed(seed)
+        a, q_list = uct_search(g["c%d_board" % ci].astype(np.float64), turn, num_mcts)
+        assert a == max_action, "case %d" % ci
+        gq = g["c%d_q" % ci]
+        assert sorted(q_list) == [(0, i) for i in range(9) if gq[i] != -np.inf]
+        for (_, i), v in q_list.items():
+            assert v == gq[i], "case %d child %d" % (ci, i)
+        st = random.getstate()[1]
+        assert st[624] == pos
+        np.testing.assert_array_equal(np.array(st[:624], np.uint32), g["c%d_mt" % ci])
+
+
+@pytest.mark.parametrize("board,sims,games", [(3, 1500, 64), (3, 200, 256), (5, 120, 16), (9, 60, 8)])
+def test_tictactoe_uct_many_boards_match_oracle(oracle, board, sims, games):
+    from alpha_omok_amd.tictactoe import TttEngine
+    rs = np.random.RandomState(board * 7 + sims)
+    wm = 3 if board == 3 else 5
+    eng = TttEngine(sims, games=games, board_size=board)
+    boards = np.zeros((games, board, board), np.int8)
+    turns = np.zeros(games, np.int32)
+    for g in range(games):
+        for _ in range(200):
+            k = int(rs.randint(0, board * board - 1))
+            cells = rs.permutation(board * board)[:k]
+            b = np.zeros(board * board, np.int8)
+            b[cells[0::2]] = 1
+            b[cells[1::2]] = -1
+            if oracle.check_win(b.reshape(board, board), wm) == 0:
+                break
+        boards[g] = b.reshape(board, board)
+        turns[g] = k % 2
+        eng.seed(g, 500 + g)
+    act, q, n = eng.search(boards, turns)
+    for g in range(games):
+        rng = oracle.PyRandom(500 + g)
+        oa, oq, on = oracle.ttt_search(boards[g], int(turns[g]), sims, rng, win_mark=wm)
+        assert act[g] == oa, "game %d" % g
+        np.testing.assert_array_equal(q[g], oq, err_msg="game %d" % g)
+        np.testing.assert_array_equal(n[g], on, err_msg="game %d" % g)
+        mt, pos = eng.get_rng_state(g)
+        assert pos == rng.pos
+        np.testing.assert_array_equal(mt, rng.state_words())
+    eng.close()
