@@ -1,19 +1,16 @@
 #!/usr/bin/env python3
-"""Throughput of the rollout agents (PUCTAgent / UCTAgent searches, one kernel per get_pi) on the GPU and of
-the C oracle on one host core, same positions and seeds.
+"""Throughput of the rollout agents (PUCTAgent / UCTAgent searches, one kernel per get_pi) on the GPU.
     python tools/time_rollout.py [--board 9] [--sims 400] [--games 4096] [--mode 0]"""
 import argparse, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alpha_omok_amd.rollout import RolloutEngine
-from oracle import oracle_py as O   # baseline only
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--board", type=int, default=9)
 ap.add_argument("--sims", type=int, default=400)
 ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--mode", type=int, default=0)
-ap.add_argument("--cpu-searches", type=int, default=8)
 a = ap.parse_args()
 eng = RolloutEngine(a.board, a.sims, a.mode, games=a.games)
 for g in range(a.games):
@@ -27,8 +24,3 @@ for _ in range(reps):
 dt = (time.perf_counter() - t0) / reps
 print("GPU  mode %d %dx%d %d sims: %d searches in %.1f ms -> %.0f searches/s, %.2f M playouts/s" % (
     a.mode, a.board, a.board, a.sims, a.games, dt * 1e3, a.games / dt, a.games * a.sims / dt / 1e6))
-t0 = time.perf_counter()
-for g in range(a.cpu_searches):
-    O.rollout_search(a.mode, a.board, a.sims, (0,), O.Rng(g))
-dc = (time.perf_counter() - t0) / a.cpu_searches
-print("CPU oracle (1 core): %.1f ms per search -> %.1f searches/s" % (dc * 1e3, 1 / dc))
