@@ -223,35 +223,42 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
     const int lane = lane_id();
     const int k = s.ply;
     const int stm = k & 1;           // 0: black to move
-    const float colour = (stm == 0) ? 1.f : 0.f;
     const int C = p.C;
+    // the last moves as one 64-bit word: byte i = move (ply - i); extracted with shifts (an indexed
+    // byte array would live in scratch memory)
+    uint64_t last64 = 0;
+#pragma unroll
+    for (int i = 0; i < kLastMoves; ++i) last64 |= static_cast<uint64_t>(s.last[i]) << (8 * i);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
         if (cell >= p.A) continue;
-        float pl[32];
+        const bool own[2] = {bb_test(s.bb[0], cell), bb_test(s.bb[1], cell)};
+        // bit i set <=> this cell received move (ply - i)
+        unsigned recent = 0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) pl[i] = 0.f;
-        for (int j = 0; j <= C - 2; ++j) {
-            // X_{k-j}: mover of move k-j is the opponent of the side to move when j is even
-            float v = 0.f;
-            if (k - j >= 1) {
-                const int col = (j & 1) ? stm : (stm ^ 1);
-                bool on = bb_test(s.bb[col], cell);
-                for (int i = j - 2; i >= 0; i -= 2) on = on && (s.last[i] != cell);
-                v = on ? 1.f : 0.f;
-            }
-            pl[C - 2 - j] = v;
-        }
-        pl[C - 1] = colour;
+        for (int i = 0; i < kLastMoves; ++i) recent |= (static_cast<int>((last64 >> (8 * i)) & 0xFF) == cell) ? (1u << i) : 0u;
+        // plane q: q == C-1 colour; q < C-1: X_{k-j}, j = C-2-q -- the stones of the player who made move
+        // k-j as they stood after it: that player's stones now, minus his moves k-j+2, k-j+4, ... (the last
+        // j-2, j-4, ... entries of the history, same parity as j)
+        auto plane = [&](int q) -> float {
+            if (q >= C) return 0.f;
+            if (q == C - 1) return (stm == 0) ? 1.f : 0.f;
+            const int j = C - 2 - q;
+            if (k - j < 1) return 0.f;
+            const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
+            // later moves of the same player: history entries j-2, j-4, ..., i.e. bits of `recent` below j with j's parity
+            const unsigned later = recent & ((1u << j) - 1u) & ((j & 1) ? 0xAAu : 0x55u);
+            return (own[col] && later == 0u) ? 1.f : 0.f;
+        };
         if (p.batch_nchw) {
-            for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = pl[q];
+            for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = plane(q);
         }
         if (p.batch_il) {
             const size_t grp = static_cast<size_t>(g / p.il_group);
             const int b = g % p.il_group;
             for (int cq = 0; cq < p.nchq; ++cq) {
-                float4 v4 = make_float4(pl[4 * cq], pl[4 * cq + 1], pl[4 * cq + 2], pl[4 * cq + 3]);
+                const float4 v4 = make_float4(plane(4 * cq), plane(4 * cq + 1), plane(4 * cq + 2), plane(4 * cq + 3));
                 float4* dst = reinterpret_cast<float4*>(p.batch_il) +
                               (((grp * p.A + cell) * p.nchq + cq) * p.il_group + b);
                 *dst = v4;
@@ -266,15 +273,19 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
 template <int NCH>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/) {
     const int lane = lane_id();
-    if ((p.active && !p.active[g]) || p.sims_done[g] >= p.sims_target[g]) {
+    // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
+    // overlap them with), so every step requests all it can in ONE trip: first the game header ...
+    const int is_active = p.active ? p.active[g] : 1;
+    const int done = p.sims_done[g], target = p.sims_target[g];
+    const int arena = p.cur[g];
+    int node = p.root_node[g];
+    if (!is_active || done >= target) {
         if (lane == 0) p.leaf_status[g] = LS_IDLE;
         return;
     }
     MtDev mt;
     mt.open(p.mt + static_cast<size_t>(g) * 624, p.mtpos + g, s_mt);
 
-    const int arena = p.cur[g];
-    int node = p.root_node[g];
     int depth = 0;
     int status = LS_EXPAND_ROOT;
     unsigned levels = 0, ties = 0;
@@ -284,15 +295,30 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     } else {
         for (;;) {
             const size_t slot = node_slot(p, arena, g, node);
-            const Pos m = p.meta[slot];
-            const int L = m.nchild;
             const size_t eb = slot * p.Ap;
-            int n[NCH];
+            // ... then, per level, the node record together with all five edge rows. The rows are Ap
+            // wide, so the addresses do not depend on the child count; lanes past it are masked after
+            // the loads (CH and ACT of the chosen edge then come from a lane shuffle, not from memory).
+            const Pos m = p.meta[slot];
+            int n[NCH], chv[NCH], acv[NCH];
+            float qv[NCH];
+            double pv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int e = lane + 64 * c;
+                const bool in = e < p.Ap;
+                n[c] = in ? p.N[eb + e] : 0;
+                qv[c] = in ? p.Q[eb + e] : 0.f;
+                pv[c] = in ? p.P[eb + e] : 0.0;
+                chv[c] = in ? p.CH[eb + e] : CH_UNVISITED;
+                acv[c] = in ? static_cast<int>(p.ACT[eb + e]) : 0;
+            }
+            const int L = m.nchild;
             int tot = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int e = lane + 64 * c;
-                n[c] = (e < L) ? p.N[eb + e] : 0;
+                n[c] = (e < L) ? n[c] : 0;
                 tot += n[c];
             }
             tot = wave_sum_i(tot);
@@ -305,10 +331,9 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                 const int e = lane + 64 * c;
                 sc[c] = -1.0e300;
                 if (e < L) {
-                    const double q = static_cast<double>(p.Q[eb + e]);
-                    const double pr = p.P[eb + e];
+                    const double q = static_cast<double>(qv[c]);
                     // u = c_puct * p * sqrt(total_n) / (n + 1)   (agents.py:158, left to right)
-                    double t = __dmul_rn(p.c_puct, pr);
+                    double t = __dmul_rn(p.c_puct, pv[c]);
                     t = __dmul_rn(t, sq);
                     const double u = __ddiv_rn(t, static_cast<double>(n[c] + 1));
                     sc[c] = __dadd_rn(q, u);
@@ -336,7 +361,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                     else r -= cnt;
                 }
             }
-            if (esel < 0 || depth >= p.maxd) {  // cannot happen for a consistent tree
+            if (esel < 0 || depth >= p.maxd) {  // NaN priors (policy summed to 0) or an inconsistent tree
                 if (lane == 0) { atomicOr(&p.err[g], ERR_PATH); p.leaf_status[g] = LS_IDLE; }
                 mt.close();
                 return;
@@ -347,12 +372,16 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             }
             ++depth;
             ++levels;
-            const int ch = p.CH[eb + esel];
+            int ch = CH_UNVISITED, a = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int cv = __shfl(chv[c], esel & 63), av = __shfl(acv[c], esel & 63);
+                if ((esel >> 6) == c) { ch = cv; a = av; }
+            }
             if (ch >= 0) { node = ch; continue; }
             if (ch == CH_TERMINAL) { status = LS_TERMINAL; break; }
             // first visit of this child: build its position, test for the end of the game
             lp = m;
-            const int a = p.ACT[eb + esel];
             pos_place(lp, a);
             const int w = win_after_move(lp, a, p.B, p.win_mark);
             if (w != 0) {
@@ -488,27 +517,37 @@ template <int NCH>
 __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const int g, uint8_t* s_ord /*[256]*/,
                                                    double* s_prior /*[256]*/, int16_t* s_tab /*[256]*/) {
     const int lane = lane_id();
+    // one memory round trip for everything that depends only on the game: leaf record, evaluation,
+    // the first 64 path entries (see select_game on why the trips are batched)
+    const size_t pbase = static_cast<size_t>(g) * p.maxd;
     const int status = p.leaf_status[g];
-    if (status == LS_IDLE) return;
     const int arena = p.cur[g];
     const int depth = p.path_len[g];
+    const int newn = p.nodes_used[g];
+    const int done = p.sims_done[g];
+    Pos lp = p.leaf_pos[g];
+    const float v_eval = p.value[g];
+    float pol[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int cell = lane + 64 * c;
+        pol[c] = (cell < p.A) ? p.policy[static_cast<size_t>(g) * p.A + cell] : 0.f;
+    }
+    const int pn0 = (lane < p.maxd) ? p.path_node[pbase + lane] : 0;
+    const int pe0 = (lane < p.maxd) ? static_cast<int>(p.path_edge[pbase + lane]) : 0;
+    if (status == LS_IDLE) return;
     float v = 0.f;
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
-        const int newn = p.nodes_used[g];
         if (newn >= p.cap) {
             if (lane == 0) { atomicOr(&p.err[g], ERR_NODE_CAP); p.sims_done[g] = p.sims_target[g]; }
             return;
         }
-        Pos lp = p.leaf_pos[g];
         const int L = legal_order<NCH>(lp, p.A, s_ord, s_tab);
         // prior_prob = zeros(A); prior_prob[a] = policy[a] for legal a (agents.py:183-187)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int cell = lane + 64 * c;
-            if (cell < p.A)
-                s_prior[cell] = pos_occupied(lp, cell)
-                                    ? 0.0
-                                    : static_cast<double>(p.policy[static_cast<size_t>(g) * p.A + cell]);
+            if (cell < p.A) s_prior[cell] = pos_occupied(lp, cell) ? 0.0 : static_cast<double>(pol[c]);
         }
         wsync();
         const double sum = pairwise_sum_dev(s_prior, p.A);  // prior_prob.sum() (agents.py:189)
@@ -534,26 +573,32 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
                 p.ACT[eb + i] = static_cast<uint8_t>(a);
             }
         }
+        // link from the parent edge (the last path entry)
+        int pn = 0, pe = 0;
+        if (status == LS_EXPAND) {
+            if (depth - 1 < 64) {
+                pn = __shfl(pn0, depth - 1);
+                pe = __shfl(pe0, depth - 1);
+            } else {
+                pn = p.path_node[pbase + depth - 1];
+                pe = p.path_edge[pbase + depth - 1];
+            }
+        }
         if (lane == 0) {
             lp.nchild = static_cast<int16_t>(L);
             p.meta[slot] = lp;
             p.nodes_used[g] = newn + 1;
-            if (status == LS_EXPAND) {
-                const int pn = p.path_node[static_cast<size_t>(g) * p.maxd + depth - 1];
-                const int pe = p.path_edge[static_cast<size_t>(g) * p.maxd + depth - 1];
-                p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
-            } else {
-                p.root_node[g] = newn;
-            }
+            if (status == LS_EXPAND) p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
+            else p.root_node[g] = newn;
         }
-        v = p.value[g];
+        v = v_eval;
     }
     // backup (agents.py:223-239): the edge into the leaf gets -v (or +1 for a terminal leaf,
     // draws included), the sign alternates towards the root. The root's own record is not kept.
     const bool terminal = (status == LS_TERMINAL);
     for (int d = lane; d < depth; d += 64) {
-        const int nd = p.path_node[static_cast<size_t>(g) * p.maxd + d];
-        const int e = p.path_edge[static_cast<size_t>(g) * p.maxd + d];
+        const int nd = (d < 64) ? pn0 : p.path_node[pbase + d];
+        const int e = (d < 64) ? pe0 : static_cast<int>(p.path_edge[pbase + d]);
         const int cnt = depth - 1 - d;
         float s;
         if (terminal) s = (cnt & 1) ? -1.f : 1.f;
@@ -565,7 +610,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         p.W[idx] = w;
         p.Q[idx] = __fdiv_rn(w, static_cast<float>(n));
     }
-    if (lane == 0) p.sims_done[g] = p.sims_done[g] + 1;
+    if (lane == 0) p.sims_done[g] = done + 1;
 }
 
 
