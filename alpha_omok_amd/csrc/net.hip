@@ -40,6 +40,9 @@ namespace ao {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
 struct Frag {
     float v[4];
 };
@@ -226,7 +229,9 @@ struct TrunkArgs {
 // fragments of tap row dy are re-loaded for the next step right after their last MFMA.
 // When input row yi is done, output row yi-1 is complete: its epilogue (BN scale/shift, residual,
 // ReLU, store) runs and the window slides (accumulator registers move down one row).
-template <int BW, int XT, int TPW>
+// OUT16: the epilogue writes the split-fp16 activation layout of k_trunk16h instead of fp32
+// (used for conv1, whose input planes are fp32; never combined with RES).
+template <int BW, int XT, int TPW, bool OUT16 = false>
 __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
                                             const float4* __restrict__ wt, const float4* __restrict__ scp,
                                             const float4* __restrict__ shp, const bool RES, int cqi, int cq_real,
@@ -354,7 +359,24 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
                     // and the compiler only inserts the wait states that protects them from the
                     // next VALU write when soffset is NOT an SGPR. With an SGPR soffset the rows
                     // of boards 12-15 (the last data beat) were overwritten on gfx950.
-                    if (xo < BW)
+                    if (OUT16) {
+                        // couts 4*kq..4*kq+3 of tile ct = halfs (kq&1)*4.. of oct (ct&1)*2 + (kq>>1) of 32-channel block ct>>1
+                        if (xo < BW) {
+                            const float f[4] = {fmaxf(vx, 0.f), fmaxf(vy, 0.f), fmaxf(vz, 0.f), fmaxf(vw, 0.f)};
+                            half4 hh, hl;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                hh[r] = static_cast<_Float16>(f[r]);
+                                hl[r] = static_cast<_Float16>(f[r] - static_cast<float>(hh[r]));
+                            }
+                            const int ct = ct0 + tl;
+                            char* base = reinterpret_cast<char*>(dst) +
+                                         ((((gbase + yo * BW + xo) * (COUT >> 5) + (ct >> 1)) * 2) * 64 +
+                                          ((ct & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+                            *reinterpret_cast<half4*>(base) = hh;
+                            *reinterpret_cast<half4*>(base + 1024) = hl;
+                        }
+                    } else if (xo < BW)
                         __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, lane_x + orow + (xo * CQO + tl * 4) * GB * 16, 0, 0);
                 }
             }
@@ -395,8 +417,9 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
 // Policy and value heads of one 16-board group inside the resident kernel (model.py:34-73):
 // 1x1 convs + BN + ReLU into LDS (flatten order c*A + cell, as the reference's .view), then one
 // wave per board: policy_fc + softmax, value_fc1 + ReLU + value_fc2 + tanh.
-template <int BW>
-__device__ __forceinline__ void trunk_heads(const TrunkArgs& a, const float4* act, size_t gbase, int grp) {
+// H16: the activations are in the split-fp16 layout of k_trunk16h (x = high half + low half)
+template <int BW, bool H16 = false, typename Args = TrunkArgs>
+__device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, size_t gbase, int grp) {
     constexpr int A = BW * BW;
     constexpr int GB = 16;
     constexpr int NA = (A + 63) / 64;
@@ -413,7 +436,21 @@ __device__ __forceinline__ void trunk_heads(const TrunkArgs& a, const float4* ac
             const float4* xp = act + ((gbase + cell) * CQ) * GB + b;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int cq = 0; cq < CQ; ++cq) {
-                const float4 x = xp[static_cast<size_t>(cq) * GB];
+                float4 x;
+                if (H16) {
+                    // [cell][c32][split][kq 4][board 16][8 halfs]: quad cq = halfs (cq&1)*4.. of oct (cq&7)>>1 of block cq>>3
+                    const char* base = reinterpret_cast<const char*>(act) +
+                                       ((((gbase + cell) * (CQ >> 3) + (cq >> 3)) * 2) * 64 + ((cq & 7) >> 1) * 16 + b) * 16 +
+                                       (cq & 1) * 8;
+                    const half4 hh = *reinterpret_cast<const half4*>(base);
+                    const half4 hl = *reinterpret_cast<const half4*>(base + 1024);
+                    x = make_float4(static_cast<float>(hh[0]) + static_cast<float>(hl[0]),
+                                    static_cast<float>(hh[1]) + static_cast<float>(hl[1]),
+                                    static_cast<float>(hh[2]) + static_cast<float>(hl[2]),
+                                    static_cast<float>(hh[3]) + static_cast<float>(hl[3]));
+                } else {
+                    x = xp[static_cast<size_t>(cq) * GB];
+                }
                 const float* w0 = s_w3 + 4 * cq;
                 const float* w1 = s_w3 + planes + 4 * cq;
                 const float* w2 = s_w3 + 2 * planes + 4 * cq;
@@ -504,6 +541,199 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// k_trunk16h -- the group-resident trunk with the fp32 contraction carried by fp16 MFMAs.
+//
+// Every fp32 operand is split into two halves, x = xh + xl (xh = fp16(x), xl = fp16(x - xh)),
+// and x*w is formed as xh*wh + xh*wl + xl*wh with v_mfma_f32_16x16x32_f16: each fp16 x fp16
+// product is exact in fp32 and the accumulation is fp32, so the only departure from an fp32
+// contraction is the dropped xl*wl term, <= 2^-22 of the product (fp32's own rounding is 2^-24).
+// Weights are pre-scaled by a power of two per layer (undone exactly in the BatchNorm scale) so
+// that their low halves stay normal numbers. Three fp16 MFMAs do the work of eight fp32 MFMAs at
+// half the cycles each: 5.3x fewer matrix-pipe cycles than k_trunk16.
+//
+// That only pays if the operands keep up (2 KB per 16-cycle MFMA), hence a different tiling:
+//   * 4 waves per workgroup, ONE per SIMD, 512 registers each; a wave owns one 16-channel output
+//     tile and the layer is done in two passes (tiles 0-3, then 4-7);
+//   * the HIGH halves of the wave's weights -- 9 taps x 128 input channels, 36 fragments, 144
+//     registers -- are loaded once per pass and stay in registers for all rows; the low halves
+//     (used once per cell row) stream from L2, one 32-channel block ahead;
+//   * activations are shared by the four waves through LDS: one input row (9 cells x 128 channels
+//     x 16 boards x {high, low} = 72 KB) is staged while the previous one is consumed (144 KB of
+//     the CU's 160 KB), and each fragment read from LDS feeds all nine taps (27 MFMAs);
+//   * same sliding window of three output rows as the fp32 kernel (108 accumulator registers).
+// Layout of a group's activations: [cell][32-channel block][half: high, low][k-oct 4][board 16][8 x fp16]
+// (a fragment = 1 KB = one B operand of the MFMA: lane = oct*16 + board holds 8 consecutive channels).
+// ----------------------------------------------------------------------------------------------
+struct TrunkHLayer {
+    const uint4* wh;   // [tap 9][c32][tile][lane 64] 8 x fp16: high halves, lane = oct*16 + cout
+    const uint4* wl;   // low halves
+    const float4* sc;  // BatchNorm scale x 2^-s (s = the layer's weight pre-scale)
+    const float4* sh;
+};
+
+struct TrunkHArgs {
+    uint4* bufA;  // conv1 output / ResBlock input-output (split-fp16 layout)
+    uint4* bufB;
+    int nlayers;  // trunk convs after conv1: 2 * n_block
+    int CQ, COUT;
+    const float *w3, *sc3, *sh3, *wp_t, *bp, *w1_t, *b1, *w2, *b2;
+    float* policy;
+    float* value;
+    TrunkHLayer layers[kMaxTrunkLayers];
+};
+
+template <int BW, int NC32>
+__global__ __launch_bounds__(256, 1) void k_trunk16h(TrunkHArgs a) {
+    constexpr int A = BW * BW;
+    constexpr int NT = NC32 * 2;             // 16-channel output tiles
+    constexpr int NFR = BW * NC32 * 2;       // activation fragments per board row
+    constexpr int STG = (NFR / 4 + NC32 - 1) / NC32;  // fragments one wave stages per 32-channel block
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][NFR][64] uint4
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int kq = lane >> 4, b = lane & 15;
+    const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first fragment of this group
+
+    for (int l = 0; l < a.nlayers; ++l) {
+        // l even: first conv of a ResBlock (x -> t); l odd: second conv (t -> x, + x in place)
+        const uint4* src = ((l & 1) ? a.bufB : a.bufA) + gfrag * 64;
+        uint4* dst = ((l & 1) ? a.bufA : a.bufB) + gfrag * 64;
+        const bool RES = (l & 1) != 0;
+        const TrunkHLayer L = a.layers[l];
+        for (int pass = 0; pass < NT / 4; ++pass) {
+            const int tile = pass * 4 + wave;
+            const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+            // weights, high halves: resident for the whole pass
+            half8 wh[9][NC32];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int c = 0; c < NC32; ++c) {
+                    const uint4 v = L.wh[((static_cast<size_t>(t) * NC32 + c) * NT + tile) * 64 + lane];
+                    wh[t][c] = __builtin_bit_cast(half8, v);
+                }
+            auto load_wl = [&](int c, half8 (&W)[9]) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const uint4 v = L.wl[((static_cast<size_t>(t) * NC32 + c) * NT + tile) * 64 + lane];
+                    W[t] = __builtin_bit_cast(half8, v);
+                }
+            };
+            f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            // stage input row 0 (each wave copies every fourth fragment)
+            __syncthreads();  // the previous pass / layer is done with both row buffers
+            for (int f = wave; f < NFR; f += 4) s_x[f * 64 + lane] = src[static_cast<size_t>(f) * 64 + lane];
+            __syncthreads();
+
+            auto epilogue = [&](int yo) {
+#pragma unroll
+                for (int i = 0; i < BW; ++i) {
+                    const f32x4 c = acc[0][i];
+                    float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z),
+                                  fmaf(c[3], sc.w, sh.w)};
+                    char* base = reinterpret_cast<char*>(dst) +
+                                 (((static_cast<size_t>(yo * BW + i) * NC32 + (tile >> 1)) * 2) * 64 +
+                                  ((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+                    if (RES) {
+                        const half4 rh = *reinterpret_cast<const half4*>(base);
+                        const half4 rl = *reinterpret_cast<const half4*>(base + 1024);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+                    }
+                    half4 hh, hl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaxf(f[r], 0.f);
+                        hh[r] = static_cast<_Float16>(v);
+                        hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+                    }
+                    *reinterpret_cast<half4*>(base) = hh;
+                    *reinterpret_cast<half4*>(base + 1024) = hl;
+                }
+            };
+
+            half8 wlA[9], wlB[9];
+            load_wl(0, wlA);
+            for (int yi = 0; yi < BW; ++yi) {
+                const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
+                uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
+                const uint4* gn = src + static_cast<size_t>(yi + 1) * NFR * 64;         // next row in HBM/L2
+                const bool more = yi + 1 < BW;
+#pragma unroll
+                for (int c = 0; c < NC32; ++c) {
+                    // low halves of the weights for the NEXT block (next row's block 0 after the last one)
+                    half8 (&wl)[9] = (c & 1) ? wlB : wlA;
+                    half8 (&wn)[9] = (c & 1) ? wlA : wlB;
+                    load_wl((c + 1) % NC32, wn);
+                    // this wave's share of the next input row, a quarter per block
+                    uint4 stg[STG];
+#pragma unroll
+                    for (int k = 0; k < STG; ++k) {
+                        const int f = wave + 4 * (c * STG + k);
+                        stg[k] = (more && f < NFR) ? gn[static_cast<size_t>(f) * 64 + lane] : make_uint4(0, 0, 0, 0);
+                    }
+                    half8 xh = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 0) * 64 + lane]);
+                    half8 xl = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 1) * 64 + lane]);
+#pragma unroll
+                    for (int xi = 0; xi < BW; ++xi) {
+                        half8 nh = xh, nl = xl;
+                        if (xi + 1 < BW) {
+                            nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 0) * 64 + lane]);
+                            nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 1) * 64 + lane]);
+                        }
+                        // input cell (yi, xi) feeds output rows yi+1-dy at cells xi-dx+1; products ordered so that
+                        // consecutive MFMAs hit different accumulators
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int yo = yi + 1 - dy;
+                            if (yo < 0 || yo >= BW) continue;   // (runtime yi: a uniform branch)
+#pragma unroll
+                            for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                                for (int dx = 0; dx < 3; ++dx) {
+                                    const int i = xi - dx + 1;
+                                    if (i < 0 || i >= BW) continue;
+                                    const half8 wv = (pr == 1) ? wl[dy * 3 + dx] : wh[dy * 3 + dx][c];
+                                    const half8 xv = (pr == 2) ? xl : xh;
+                                    acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[2 - dy][i], 0, 0, 0);
+                                }
+                            }
+                        }
+                        xh = nh;
+                        xl = nl;
+                    }
+#pragma unroll
+                    for (int k = 0; k < STG; ++k) {
+                        const int f = wave + 4 * (c * STG + k);
+                        if (more && f < NFR) xn[f * 64 + lane] = stg[k];
+                    }
+                }
+                if (yi >= 1) epilogue(yi - 1);
+#pragma unroll
+                for (int i = 0; i < BW; ++i) {
+                    acc[0][i] = acc[1][i];
+                    acc[1][i] = acc[2][i];
+                    acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();  // next row staged by all waves; this row's buffer free
+            }
+            epilogue(BW - 1);
+        }
+        // layer boundary inside the workgroup (see k_trunk16)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Small batches (a drop-in ZeroAgent has ONE game): boards cannot fill the MFMA N dimension, so
 // the CELLS of one board do:   D[cout 16][cell 16] += Wt[cout 16][k 4] * X[k 4][cell 16]
 // on the plain per-board NHWC layout act[board][cell][channel]. One wave per (16 cells, 16 output
@@ -540,7 +770,7 @@ struct LayerArgs {
     int res, cqi, cq_real, COUT, nch;
 };
 
-template <int BW, int XT>
+template <int BW, int XT, bool OUT16 = false>
 __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
     constexpr int A = BW * BW;
     const int grp = blockIdx.x / a.nch;
@@ -550,8 +780,8 @@ __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
     const int ye = yb + base + (c < extra ? 1 : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-    trunk_layer<BW, XT, 1>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real, a.COUT,
-                           static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
+    trunk_layer<BW, XT, 1, OUT16>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real,
+                                  a.COUT, static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
 }
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
@@ -677,6 +907,10 @@ struct ao_net {
     std::vector<void*> allocs;
     // device parameters
     std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]; conv_w[0] packed for nchq32
+    // split-fp16 trunk (mode 5): per trunk conv after conv1 the high / low weight halves (pre-scaled by a
+    // power of two) and the BatchNorm scale with that power of two folded back
+    std::vector<uint4*> convh_wh, convh_wl;
+    std::vector<float*> convh_sc;
     float* conv0_w16 = nullptr;                    // conv1 weights packed for nchq16
     float* conv0_w1 = nullptr;                     // conv1 weights packed for nchq1 (per-board NHWC path)
     int nchq1 = 0;                                 // input channel quads of the per-board path: multiple of 4
@@ -789,7 +1023,7 @@ int pick_mode_public(const ao_net* n, int boards) { return pick_mode(n, boards, 
 
 void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
     const int mode = pick_mode(n, boards, nullptr);
-    if (mode == 2 || mode == 4) { *group = 16; *nchq = n->nchq16; }
+    if (mode == 2 || mode == 4 || mode == 5) { *group = 16; *nchq = n->nchq16; }
     else if (mode == 3) { *group = 1; *nchq = n->nchq1; }
     else { *group = 32; *nchq = n->nchq32; }
 }
@@ -926,6 +1160,53 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                            reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
         return 0;
+    } else if (group == 16 && mode == 5) {
+        // split-fp16 resident trunk: conv1 (fp32 planes in, K = 32) runs on the fp32 window kernel and writes
+        // the split layout; one resident launch then carries every group through the ResBlocks and the heads
+        LayerArgs c1;
+        c1.src = reinterpret_cast<const float4*>(in_il);
+        c1.dst = reinterpret_cast<float4*>(n->act_x);
+        c1.layer.w = reinterpret_cast<const float4*>(n->conv0_w16);
+        c1.layer.sc = reinterpret_cast<const float4*>(n->conv_sc[0]);
+        c1.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[0]);
+        c1.res = 0; c1.cqi = n->nchq16; c1.cq_real = (n->C + 3) / 4; c1.COUT = n->planes; c1.nch = 1;
+        TrunkHArgs a;
+        a.bufA = reinterpret_cast<uint4*>(n->act_x);
+        a.bufB = reinterpret_cast<uint4*>(n->act_t);
+        a.nlayers = 2 * n->nb;
+        a.CQ = n->CQ;
+        a.COUT = n->planes;
+        a.w3 = n->head_w3; a.sc3 = n->head_sc3; a.sh3 = n->head_sh3;
+        a.wp_t = n->wp_t; a.bp = n->bp; a.w1_t = n->w1_t; a.b1 = n->b1; a.w2 = n->w2; a.b2 = n->b2;
+        a.policy = policy;
+        a.value = value;
+        for (int l = 0; l < a.nlayers; ++l) {
+            a.layers[l].wh = n->convh_wh[l];
+            a.layers[l].wl = n->convh_wl[l];
+            a.layers[l].sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
+            a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l + 1]);
+        }
+        static bool attr_done[16] = {};
+        const int idx = n->timing ? timer_begin(n, s) : 0;
+        switch (n->B) {
+#define AO_BW_CASE(W)                                                                                        \
+    case W: {                                                                                                \
+        constexpr size_t lds_ = static_cast<size_t>(2) * W * 4 * 2 * 1024;                                   \
+        if (!attr_done[W]) {                                                                                 \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
+            attr_done[W] = true;                                                                             \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_layer16<W, W, true>), dim3(groups), dim3(512), 0, s, c1);                      \
+        hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(256), lds_, s, a);                         \
+    } break;
+            AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+#undef AO_BW_CASE
+            default: return n->fail("split-fp16 trunk: board larger than 9x9");
+        }
+        if (n->timing) timer_end(n, idx, s);
+        NET_HIP(n, hipGetLastError());
+        return 0;  // the heads ran inside the resident kernel
     } else if (group == 16 && mode == 4) {
         auto layer = [&](int l, const float* in, int cqi, int cq_real, bool res, float* out) {
             LayerArgs a;
@@ -1045,9 +1326,13 @@ void ao_net_destroy(ao_net* n) {
     delete n;
 }
 
+static bool h16_supported(const ao_net* n);
+
 int ao_net_set_mode(ao_net* n, int mode) {
-    if (mode < 0 || mode > 4)
-        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board) or 4 (row-chunked)");
+    if (mode < 0 || mode > 5)
+        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board), 4 (row-chunked) or 5 (split-fp16 trunk)");
+    if (mode == 5 && !h16_supported(n))
+        return n->fail("mode 5 (split-fp16 resident trunk) needs 128 planes, a board of at most 9x9 and at least one ResBlock");
     n->mode = mode;
     return 0;
 }
@@ -1095,12 +1380,35 @@ static std::vector<float> pack_conv(const std::vector<float>& w, int cout, int c
     return packed;
 }
 
+// OIHW fp32 -> two fp16 planes [tap][c32][tile][oct 4][cout 16][8]: w * 2^s = high + low
+static void pack_conv_h(const std::vector<float>& w, int cout, int cin, int s, std::vector<uint16_t>* hi,
+                        std::vector<uint16_t>* lo) {
+    const int nc32 = cin / 32, nt = cout / 16;
+    hi->assign(static_cast<size_t>(9) * nc32 * nt * 64 * 8, 0);
+    lo->assign(hi->size(), 0);
+    const float scale = std::ldexp(1.0f, s);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < 9; ++t) {
+                const float v = w[(static_cast<size_t>(co) * cin + ci) * 9 + t] * scale;
+                const _Float16 h = static_cast<_Float16>(v);
+                const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+                const size_t idx = ((((static_cast<size_t>(t) * nc32 + ci / 32) * nt + co / 16) * 4 + (ci % 32) / 8) * 16 +
+                                    co % 16) * 8 + ci % 8;
+                std::memcpy(&(*hi)[idx], &h, 2);
+                std::memcpy(&(*lo)[idx], &l, 2);
+            }
+}
+
+static bool h16_supported(const ao_net* n) { return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 2 * n->nb <= ao::kMaxTrunkLayers; }
+
 int ao_net_finalize(ao_net* n) {
     NET_HIP(n, hipSetDevice(n->device));
     NET_HIP(n, hipDeviceSynchronize());
     for (void* p : n->allocs) hipFree(p);
     n->allocs.clear();
     n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
+    n->convh_wh.clear(); n->convh_wl.clear(); n->convh_sc.clear();
     n->ws_boards = 0;
     const int P = n->planes, A = n->A;
     auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
@@ -1124,6 +1432,36 @@ int ao_net_finalize(ao_net* n) {
         const std::string pre = "layers." + std::to_string(i);
         if (add_conv(pre + ".conv1.weight", pre + ".bn1", P, n->CQ)) return 1;
         if (add_conv(pre + ".conv2.weight", pre + ".bn2", P, n->CQ)) return 1;
+    }
+    if (h16_supported(n)) {
+        for (int l = 1; l <= 2 * n->nb; ++l) {
+            const std::string pre = "layers." + std::to_string((l - 1) / 2);
+            const std::string cname = pre + ((l & 1) ? ".conv1.weight" : ".conv2.weight");
+            const std::string bname = pre + ((l & 1) ? ".bn1" : ".bn2");
+            const std::vector<float>* w;
+            if (get_param(n, cname, static_cast<size_t>(P) * P * 9, &w)) return 1;
+            float mx = 0.f;
+            for (float v : *w) mx = std::max(mx, std::fabs(v));
+            // power-of-two pre-scale: largest |w| lands in [4, 8), so the low halves are normal fp16 numbers
+            const int sft = (mx > 0.f && std::isfinite(mx)) ? 2 - static_cast<int>(std::floor(std::log2(mx))) : 0;
+            std::vector<uint16_t> hi, lo;
+            pack_conv_h(*w, P, P, sft, &hi, &lo);
+            std::vector<float> sc, sh;
+            if (fold_bn(n, bname, P, &sc, &sh)) return 1;
+            for (float& v : sc) v = std::ldexp(v, -sft);
+            void *dh = nullptr, *dl = nullptr;
+            float* dsc = nullptr;
+            NET_HIP(n, hipMalloc(&dh, hi.size() * 2));
+            n->allocs.push_back(dh);
+            NET_HIP(n, hipMalloc(&dl, lo.size() * 2));
+            n->allocs.push_back(dl);
+            NET_HIP(n, hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+            NET_HIP(n, hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+            if (upload(n, &dsc, sc)) return 1;
+            n->convh_wh.push_back(static_cast<uint4*>(dh));
+            n->convh_wl.push_back(static_cast<uint4*>(dl));
+            n->convh_sc.push_back(dsc);
+        }
     }
     // heads
     const std::vector<float>*pw, *vw, *fcw, *fcb, *f1w, *f1b, *f2w, *f2b;
@@ -1213,6 +1551,10 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
  } else if (group == 16 && ao::pick_mode_public(n, boards) == 4) {
         nm = "k_layer16<" + std::to_string(n->B) + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
+    } else if (group == 16 && ao::pick_mode_public(n, boards) == 5) {
+        nm = "k_trunk16h<" + std::to_string(n->B) + "> (conv1 fp32 + " + std::to_string(2 * n->nb) +
+             " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), one resident launch)";
+        f = conv1 + 2.0 * n->nb * conv;
     } else if (group == 16) {
         nm = "k_trunk16<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
              " 3x3 convs, one launch, fp32 MFMA 16x16x4)";

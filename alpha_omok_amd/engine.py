@@ -63,7 +63,8 @@ class Net:
         return pol, val
 
     def set_mode(self, mode):
-        """0 auto, 1 layer kernels (32-board groups), 2 group-resident trunk, 3 per-board, 4 row-chunked layers."""
+        """0 auto, 1 layer kernels (32-board groups), 2 group-resident trunk, 3 per-board, 4 row-chunked layers,
+        5 group-resident trunk on split-fp16 MFMAs (fp32-accurate; 128 planes, board <= 9x9)."""
         self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
 
     def dominant_kernel(self, boards):

@@ -139,7 +139,11 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
  * (medium batches), 2 = group-resident trunk: one workgroup carries 16 boards through every conv
  * layer in a single launch (4096 boards = 256 groups = one per CU), 3 = per-board NHWC with the
  * cells as the MFMA N dimension (latency path for a handful of games), 4 = one launch per layer
- * over (16-board group x row chunk) for the batch sizes in between. All fp32. */
+ * over (16-board group x row chunk) for the batch sizes in between -- all fp32 MFMA --, 5 = the
+ * group-resident trunk with the fp32 contraction carried by fp16 MFMAs: every operand is split in
+ * two halves (x = xh + xl) and x*w = xh*wh + xh*wl + xl*wh with fp32 accumulation (the dropped
+ * xl*wl term is <= 2^-22 of a product; measured error against an fp64 evaluation equals the fp32
+ * path's). Mode 5 needs 128 planes, a board of at most 9x9 and at least one ResBlock. */
 int  ao_net_set_mode(ao_net *n, int mode);
 /* total device time (ms) and launch count of the dominant trunk kernel since the last call
  * (HIP events on the launch stream); used by bench.py's roofline. */

@@ -18,13 +18,22 @@ def _native(nb, C, planes, B, seed):
     return net
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def _h16_ok(nb, B, planes):
+    """mode 5 (split-fp16 resident trunk) is built for 128 planes, boards up to 9x9, >= 1 ResBlock"""
+    return planes == 128 and B <= 9 and nb >= 1
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_golden_gv7_forward(mode):
-    """mode 1: one kernel per conv (groups of 32 boards); mode 2: group-resident trunk (16)."""
+    """mode 1: one kernel per conv (groups of 32 boards); mode 2: group-resident trunk (16); 5: split-fp16 trunk."""
     import torch
     g = load_golden("gv7_pvnet_forward")
+    ran = 0
     for i in range(int(g["count"])):
         nb, B, planes, wseed = g["cfg%d" % i].tolist()
+        if mode == 5 and not _h16_ok(nb, B, planes):
+            continue
+        ran += 1
         net = _native(nb, 5, planes, B, wseed)
         net.set_mode(mode)
         x = torch.from_numpy(g["x%d" % i]).cuda()
@@ -35,14 +44,19 @@ def test_golden_gv7_forward(mode):
         assert dp < TOL and dv < TOL, (nb, B, planes, dp, dv)
         assert abs(p.sum(dim=1).cpu().numpy() - 1).max() < 1e-5
         net.close()
+    if mode == 5 and ran == 0:
+        pytest.skip("no 128-plane / <= 9x9 case in the fixture")
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("nb,B,planes,batch", [(4, 9, 128, 70), (10, 9, 128, 33), (2, 15, 128, 40),
-                                               (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64)])
+                                               (3, 9, 64, 32), (1, 3, 32, 5), (2, 7, 96, 64), (2, 7, 128, 20),
+                                               (1, 3, 128, 3)])
 def test_forward_vs_torch_fp32(nb, B, planes, batch, mode):
     import torch
     from alpha_omok_amd.pvnet import PVNet
+    if mode == 5 and not _h16_ok(nb, B, planes):
+        pytest.skip("split-fp16 trunk: 128 planes, board <= 9x9 only")
     sd = pvnet_weights.make_state_dict(nb, 5, planes, B, 100 + nb)
     ref = PVNet(nb, 5, planes, B)
     ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -139,7 +153,7 @@ def test_full_size_batch_all_paths_agree():
     xt = torch.from_numpy(x).cuda()
     net = ref.to_native(0)
     outs = {}
-    for mode in (2, 1, 3, 4, 2, 2):
+    for mode in (2, 1, 3, 4, 5, 2, 5, 2, 5):
         net.set_mode(mode)
         p, v = net(xt)
         torch.cuda.synchronize()
@@ -149,12 +163,13 @@ def test_full_size_batch_all_paths_agree():
             np.testing.assert_array_equal(outs[mode][0], p)      # same path twice: bit-identical
             np.testing.assert_array_equal(outs[mode][1], v)
         outs[mode] = (p, v)
-    for m in (1, 3, 4):
+    for m in (1, 3, 4, 5):
         assert np.abs(outs[2][0] - outs[m][0]).max() < 2e-5, m
         assert np.abs(outs[2][1] - outs[m][1]).max() < 2e-5, m
     idx = rs.choice(batch, 96, replace=False)
     with torch.no_grad():
         rp, rv = ref(torch.from_numpy(x[idx]))
-    assert np.abs(outs[2][0][idx] - rp.numpy()).max() < TOL
-    assert np.abs(outs[2][1][idx] - rv.numpy()).max() < TOL
+    for m in (2, 5):
+        assert np.abs(outs[m][0][idx] - rp.numpy()).max() < TOL, m
+        assert np.abs(outs[m][1][idx] - rv.numpy()).max() < TOL, m
     net.close()
