@@ -551,15 +551,15 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
 // that their low halves stay normal numbers. Three fp16 MFMAs do the work of eight fp32 MFMAs at
 // half the cycles each: 5.3x fewer matrix-pipe cycles than k_trunk16.
 //
-// That only pays if the operands keep up (2 KB per 16-cycle MFMA), hence a different tiling:
-//   * 4 waves per workgroup, ONE per SIMD, 512 registers each; a wave owns one 16-channel output
-//     tile and the layer is done in two passes (tiles 0-3, then 4-7);
-//   * the HIGH halves of the wave's weights -- 9 taps x 128 input channels, 36 fragments, 144
-//     registers -- are loaded once per pass and stay in registers for all rows; the low halves
-//     (used once per cell row) stream from L2, one 32-channel block ahead;
-//   * activations are shared by the four waves through LDS: one input row (9 cells x 128 channels
-//     x 16 boards x {high, low} = 72 KB) is staged while the previous one is consumed (144 KB of
-//     the CU's 160 KB), and each fragment read from LDS feeds all nine taps (27 MFMAs);
+// That only pays if the operands keep up (2 KB per 16-cycle MFMA):
+//   * activations are shared by the eight waves of the workgroup through LDS: one input row (9 cells x
+//     128 channels x 16 boards x {high, low} = 72 KB) is staged with LDS-direct loads while the previous
+//     one is consumed (144 KB of the CU's 160 KB);
+//   * a wave owns one 16-channel output tile, two waves per SIMD (as in k_trunk16: the other wave's
+//     MFMAs cover this wave's loads -- a one-wave-per-SIMD variant with the weights resident in 512
+//     registers ran at 37 % MFMA utilisation because every load issue was exposed);
+//   * weights stream from L2, one (32-channel block, tap row) slab = 3 taps x {high, low} ahead:
+//     18.5 B/cycle/CU, 2.5x the fp32 kernel's operand traffic;
 //   * same sliding window of three output rows as the fp32 kernel (108 accumulator registers).
 // Layout of a group's activations: [cell][32-channel block][half: high, low][k-oct 4][board 16][8 x fp16]
 // (a fragment = 1 KB = one B operand of the MFMA: lane = oct*16 + board holds 8 consecutive channels).
@@ -582,18 +582,36 @@ struct TrunkHArgs {
     TrunkHLayer layers[kMaxTrunkLayers];
 };
 
+// All global traffic of k_trunk16h goes through buffer descriptors: address = descriptor base + one
+// 32-bit per-lane offset (VGPR) + a uniform offset (SGPR). With plain pointers the compiler keeps a 64-bit
+// address VGPR pair per access site, hoists them out of the loops and spills them (270 registers in
+// the first version of this kernel).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half8 buf_ld_h8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ half4 buf_ld_h4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+
 template <int BW, int NC32>
-__global__ __launch_bounds__(256, 1) void k_trunk16h(TrunkHArgs a) {
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     constexpr int A = BW * BW;
-    constexpr int NT = NC32 * 2;             // 16-channel output tiles
+    constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
     constexpr int NFR = BW * NC32 * 2;       // activation fragments per board row
-    constexpr int STG = (NFR / 4 + NC32 - 1) / NC32;  // fragments one wave stages per 32-channel block
+    constexpr int NB = NC32 * 3;             // (32-channel block, tap row) slabs per input row
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][NFR][64] uint4
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
     const int kq = lane >> 4, b = lane & 15;
     const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first fragment of this group
+    const int lane16 = lane * 16;
+    // per-lane byte offset of this lane's 4 output channels inside a (cell, 32-channel block) fragment pair
+    const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
 
     for (int l = 0; l < a.nlayers; ++l) {
         // l even: first conv of a ResBlock (x -> t); l odd: second conv (t -> x, + x in place)
@@ -601,83 +619,82 @@ __global__ __launch_bounds__(256, 1) void k_trunk16h(TrunkHArgs a) {
         uint4* dst = ((l & 1) ? a.bufA : a.bufB) + gfrag * 64;
         const bool RES = (l & 1) != 0;
         const TrunkHLayer L = a.layers[l];
-        for (int pass = 0; pass < NT / 4; ++pass) {
-            const int tile = pass * 4 + wave;
-            const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
-            // weights, high halves: resident for the whole pass
-            half8 wh[9][NC32];
+        const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+        const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NC32 * NT * 1024u);
+        const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NC32 * NT * 1024u);
+        const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+        const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+        // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of
+        // the SIMD computes meanwhile)
+        half8 wA[2][3], wB[2][3];
+        auto load_w = [&](int slab, half8 (&W)[2][3]) {
+            const int c = (slab / 3) % NC32, dy = slab % 3;
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ub = (((dy * 3 + dx) * NC32 + c) * NT + tile) * 1024;
+                W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+                W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+            }
+        };
+        f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
 #pragma unroll
-                for (int c = 0; c < NC32; ++c) {
-                    const uint4 v = L.wh[((static_cast<size_t>(t) * NC32 + c) * NT + tile) * 64 + lane];
-                    wh[t][c] = __builtin_bit_cast(half8, v);
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto epilogue = [&](int yo) {
+#pragma unroll
+            for (int i = 0; i < BW; ++i) {
+                const f32x4 c = acc[0][i];
+                float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z),
+                              fmaf(c[3], sc.w, sh.w)};
+                const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                if (RES) {
+                    const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
+                    const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
                 }
-            auto load_wl = [&](int c, half8 (&W)[9]) {
+                half4 hh, hl;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const uint4 v = L.wl[((static_cast<size_t>(t) * NC32 + c) * NT + tile) * 64 + lane];
-                    W[t] = __builtin_bit_cast(half8, v);
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(f[r], 0.f);
+                    hh[r] = static_cast<_Float16>(v);
+                    hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
                 }
-            };
-            f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                buf_st_h4(hh, rs_dst, out_voff, ob);
+                buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+            }
+        };
 
-            // stage input row 0 (each wave copies every fourth fragment)
-            __syncthreads();  // the previous pass / layer is done with both row buffers
-            for (int f = wave; f < NFR; f += 4) s_x[f * 64 + lane] = src[static_cast<size_t>(f) * 64 + lane];
-            __syncthreads();
+        // stage input row 0 (wave w copies fragments w, w + NT, ...)
+        __syncthreads();  // the previous layer is done with both row buffers
+        for (int f = tile; f < NFR; f += NT)
+            s_x[f * 64 + lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, f * 1024, 0));
+        load_w(0, wA);
+        __syncthreads();
 
-            auto epilogue = [&](int yo) {
+        for (int yi = 0; yi < BW; ++yi) {
+            const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
+            uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
+            const int gn = (yi + 1 < BW ? yi + 1 : yi) * NFR * 1024;   // byte offset of the next row in src
 #pragma unroll
-                for (int i = 0; i < BW; ++i) {
-                    const f32x4 c = acc[0][i];
-                    float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z),
-                                  fmaf(c[3], sc.w, sh.w)};
-                    char* base = reinterpret_cast<char*>(dst) +
-                                 (((static_cast<size_t>(yo * BW + i) * NC32 + (tile >> 1)) * 2) * 64 +
-                                  ((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
-                    if (RES) {
-                        const half4 rh = *reinterpret_cast<const half4*>(base);
-                        const half4 rl = *reinterpret_cast<const half4*>(base + 1024);
+            for (int slab = 0; slab < NB; ++slab) {
+                const int c = slab / 3, dy = slab % 3;
+                half8 (&w)[2][3] = (slab & 1) ? wB : wA;
+                half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
+                load_w(slab + 1, wn);   // NB is even: the parity carries over from one row to the next
+                if (dy == 1) {
+                    // next input row straight into LDS, a share per block (always-executed slab)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+                    for (int k = 0; k < (NFR / NT + NC32 - 1) / NC32; ++k) {
+                        const int f = tile + NT * (c * ((NFR / NT + NC32 - 1) / NC32) + k);
+                        if (f < NFR)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
+                                                                 16, lane16, gn + f * 1024, 0, 0);
                     }
-                    half4 hh, hl;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fmaxf(f[r], 0.f);
-                        hh[r] = static_cast<_Float16>(v);
-                        hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
-                    }
-                    *reinterpret_cast<half4*>(base) = hh;
-                    *reinterpret_cast<half4*>(base + 1024) = hl;
                 }
-            };
-
-            half8 wlA[9], wlB[9];
-            load_wl(0, wlA);
-            for (int yi = 0; yi < BW; ++yi) {
-                const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
-                uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
-                const uint4* gn = src + static_cast<size_t>(yi + 1) * NFR * 64;         // next row in HBM/L2
-                const bool more = yi + 1 < BW;
-#pragma unroll
-                for (int c = 0; c < NC32; ++c) {
-                    // low halves of the weights for the NEXT block (next row's block 0 after the last one)
-                    half8 (&wl)[9] = (c & 1) ? wlB : wlA;
-                    half8 (&wn)[9] = (c & 1) ? wlA : wlB;
-                    load_wl((c + 1) % NC32, wn);
-                    // this wave's share of the next input row, a quarter per block
-                    uint4 stg[STG];
-#pragma unroll
-                    for (int k = 0; k < STG; ++k) {
-                        const int f = wave + 4 * (c * STG + k);
-                        stg[k] = (more && f < NFR) ? gn[static_cast<size_t>(f) * 64 + lane] : make_uint4(0, 0, 0, 0);
-                    }
+                const int yo = yi + 1 - dy;
+                if (yo >= 0 && yo < BW) {   // (uniform)
                     half8 xh = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 0) * 64 + lane]);
                     half8 xl = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 1) * 64 + lane]);
 #pragma unroll
@@ -687,44 +704,37 @@ __global__ __launch_bounds__(256, 1) void k_trunk16h(TrunkHArgs a) {
                             nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 0) * 64 + lane]);
                             nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 1) * 64 + lane]);
                         }
-                        // input cell (yi, xi) feeds output rows yi+1-dy at cells xi-dx+1; products ordered so that
-                        // consecutive MFMAs hit different accumulators
+                        // input cell (yi, xi) feeds output row yo at cells xi-dx+1: xh*wh, xh*wl, xl*wh, ordered so
+                        // that consecutive MFMAs hit different accumulators
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int yo = yi + 1 - dy;
-                            if (yo < 0 || yo >= BW) continue;   // (runtime yi: a uniform branch)
+                        for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
-                            for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-                                for (int dx = 0; dx < 3; ++dx) {
-                                    const int i = xi - dx + 1;
-                                    if (i < 0 || i >= BW) continue;
-                                    const half8 wv = (pr == 1) ? wl[dy * 3 + dx] : wh[dy * 3 + dx][c];
-                                    const half8 xv = (pr == 2) ? xl : xh;
-                                    acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, acc[2 - dy][i], 0, 0, 0);
-                                }
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int i = xi - dx + 1;
+                                if (i < 0 || i >= BW) continue;
+                                acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[pr == 1 ? 1 : 0][dx], pr == 2 ? xl : xh,
+                                                                                      acc[2 - dy][i], 0, 0, 0);
                             }
                         }
                         xh = nh;
                         xl = nl;
-                    }
-#pragma unroll
-                    for (int k = 0; k < STG; ++k) {
-                        const int f = wave + 4 * (c * STG + k);
-                        if (more && f < NFR) xn[f * 64 + lane] = stg[k];
+                        // keeps the scheduler from hoisting every LDS read of the slab to its top (72 registers)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (yi >= 1) epilogue(yi - 1);
-#pragma unroll
-                for (int i = 0; i < BW; ++i) {
-                    acc[0][i] = acc[1][i];
-                    acc[1][i] = acc[2][i];
-                    acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                __syncthreads();  // next row staged by all waves; this row's buffer free
+                __builtin_amdgcn_sched_barrier(0);
             }
-            epilogue(BW - 1);
+            if (yi >= 1) epilogue(yi - 1);
+#pragma unroll
+            for (int i = 0; i < BW; ++i) {
+                acc[0][i] = acc[1][i];
+                acc[1][i] = acc[2][i];
+                acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        epilogue(BW - 1);
         // layer boundary inside the workgroup (see k_trunk16)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1198,7 +1208,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             attr_done[W] = true;                                                                             \
         }                                                                                                    \
         hipLaunchKernelGGL((k_layer16<W, W, true>), dim3(groups), dim3(512), 0, s, c1);                      \
-        hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(256), lds_, s, a);                         \
+        hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                         \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
 #undef AO_BW_CASE
