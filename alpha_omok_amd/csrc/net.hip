@@ -992,6 +992,12 @@ static void timer_end(ao_net* n, int idx, hipStream_t s) {
     ++n->ring_count;
 }
 
+// mode 5 (k_trunk16h) is built for 128 planes, boards up to 9x9 (one input row of a 16-board group in both
+// halves = 72 KB, two of them in LDS) and at least one ResBlock
+static bool h16_supported(const ao_net* n) {
+    return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 2 * n->nb <= ao::kMaxTrunkLayers;
+}
+
 namespace ao {
 
 int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why) {
@@ -1013,7 +1019,9 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     const int g16 = (boards + 15) / 16;
     // measured cross-over of the per-board path and the row-chunked layers: 128 boards 529 vs 676 us,
     // 256 boards 979 vs 676 us per simulation (9x9, 4 blocks)
-    if (mode == 0) mode = (static_cast<long>(boards) * n->A <= 13000) ? 3 : (g16 >= 192 ? 2 : 4);
+    // big batches: the group-resident trunk, on split-fp16 MFMAs where that kernel exists (2.6x the fp32-MFMA
+    // trunk at the same accuracy), else on fp32 MFMAs
+    if (mode == 0) mode = (static_cast<long>(boards) * n->A <= 13000) ? 3 : (g16 >= 192 ? (h16_supported(n) ? 5 : 2) : 4);
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
     int nch = 1;
     if (mode == 4) {
@@ -1336,8 +1344,6 @@ void ao_net_destroy(ao_net* n) {
     delete n;
 }
 
-static bool h16_supported(const ao_net* n);
-
 int ao_net_set_mode(ao_net* n, int mode) {
     if (mode < 0 || mode > 5)
         return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board), 4 (row-chunked) or 5 (split-fp16 trunk)");
@@ -1410,7 +1416,6 @@ static void pack_conv_h(const std::vector<float>& w, int cout, int cin, int s, s
             }
 }
 
-static bool h16_supported(const ao_net* n) { return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 2 * n->nb <= ao::kMaxTrunkLayers; }
 
 int ao_net_finalize(ao_net* n) {
     NET_HIP(n, hipSetDevice(n->device));

@@ -6,18 +6,23 @@
 
 Workload (BASELINE.json configs[2], the largest single-GPU configuration; configs[3] is the same
 per GPU x 8): 9x9 Omok, 4096 concurrent self-play games per GPU, 400 MCTS simulations per move,
-one leaf per game per wave (leaf batch 4096), random-init 4-block/128-channel PVNet, fp32.
+one leaf per game per wave (leaf batch 4096), random-init 4-block/128-channel PVNet, fp32 results
+(the conv contraction runs on fp16 MFMAs with every fp32 operand split in two halves and fp32
+accumulation -- error against an fp64 evaluation equal to the fp32-MFMA path's; `--trunk-mode 2`
+selects the fp32-MFMA trunk, whose number is also reported as `fp32_mfma_trunk`).
 A "step" = one move decision (400 simulations, 401 on a game's first move) for every game of the
 rank, then utils.get_action + env step + re-rooting; finished games are reset and re-seeded.
 Games shard across ranks with no data-path collective (weak scaling); value = all ranks' move
 decisions / max-over-ranks time.
 
 The JSON line also carries:
-  roofline      the dominant kernel (the conv stack: k_trunk16, fp32 MFMA): algorithmic FLOPs per
-                launch (zero padding counted) / average launch duration from HIP
-                events on the launch stream, against the 157.3 TFLOP/s dense fp32 MFMA peak of
-                MI355X. The kernel skips the taps that fall off the board (625 of 729 per 9x9
-                board do work), so frac can exceed 1.
+  roofline      the dominant kernel (the conv stack): algorithmic FLOPs per launch (zero padding
+                counted) / average launch duration from HIP events on the launch
+                stream, against the dense MFMA peak of the instruction the kernel issues: 2500
+                TFLOP/s (fp16) for k_trunk16h, which spends THREE fp16 MFMA products per fp32
+                multiply-add (`executed_tflops` = what the matrix pipe actually does), 157.3
+                TFLOP/s for the fp32-MFMA kernels. Taps that fall off the board are skipped
+                (625 of 729 per 9x9 board do work), so the fp32 kernel's frac can exceed 1.
   cpu_baseline  the sequential per-game search (oracle/ C restatement of agents.py) with the
                 PVNet forward on PyTorch-CPU at batch 1 -- what main.self_play does -- timed on
                 this host for a bounded sample (rank 0, N=1 only).
@@ -35,6 +40,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense fp16 / bf16 MFMA
 
 
 def trunk_conv_flops(board, planes, boards):
@@ -115,7 +121,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-game", action="store_true")
-    ap.add_argument("--trunk-mode", type=int, default=0, help="0 auto, 1 layer kernels, 2 group-resident trunk")
+    ap.add_argument("--trunk-mode", type=int, default=0,
+                    help="0 auto, 1 layer kernels, 2 group-resident fp32-MFMA trunk, 3 per-board, 4 row-chunked, "
+                         "5 group-resident split-fp16 trunk")
+    ap.add_argument("--no-fp32-compare", action="store_true", help="skip the extra fp32-MFMA-trunk measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +222,8 @@ def main():
         except Exception:
             traffic = None
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
+        split16 = kname.startswith("k_trunk16h")
+        peak = PEAK_F16_MFMA_TFLOPS if split16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "self-play move-decisions/sec (9x9, 400 sims/move)",
             "value": value,
@@ -224,7 +235,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (fp16x2-split MFMA operands, 3 products per multiply-add, f32 accumulate)" if split16 else "f32",
             "data": "synthetic (self-play from the empty board, random-init weights, per-game seeds)",
             "config": {
                 "workload": "BASELINE configs[2]: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "
@@ -240,9 +251,11 @@ def main():
                 "bound": "mfma",
                 "kernel": kname,
                 "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "frac": achieved / peak,
+                "mfma_dtype": "f16" if split16 else "f32",
+                "executed_tflops": achieved * 3.0 if split16 else achieved,
                 "traffic": traffic,
                 "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)"
                                 % (os.path.relpath(traffic_src, REPO) if traffic_src else "no profile"),
@@ -252,6 +265,22 @@ def main():
                 "conv_time_share": (conv_ms * 1e-3) / dt if dt > 0 else None,
             },
         }
+        if world == 1 and split16 and not args.no_fp32_compare:
+            # the same workload with the fp32-MFMA trunk (k_trunk16), for comparison
+            try:
+                net.set_mode(2)
+                step(False)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step(False)
+                fence()
+                d1 = time.perf_counter() - t1
+                out["fp32_mfma_trunk"] = {"kernel": "k_trunk16 (fp32 MFMA 16x16x4)", "value": 2 * G / d1,
+                                          "unit": "move-decisions/s", "ms_per_step": d1 / 2 * 1e3}
+            except Exception as e:
+                out["fp32_mfma_trunk"] = {"value": None, "error": repr(e)}
+            net.set_mode(args.trunk_mode)
         if world == 1 and G > 1 and not args.no_single_game:
             # BASELINE configs[1] beside the headline: ONE game, 400 sims/move, same network
             # (latency path: per-board conv kernels, no concurrency to hide behind)
