@@ -27,10 +27,10 @@ def prof(name, extra, cmd):
     return dbs[0] if dbs else None
 
 
-bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game"]
+bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare"]
 db = prof("stats", ["--stats"], bench + ["--steps", "2", "--warmup", "1"])
 with open(os.path.join(out, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game --no-fp32-compare\n")
     f.write(subprocess.run([sys.executable, summ, "stats", db], capture_output=True, text=True).stdout)
 
 db1 = prof("single", ["--stats"], ["python", os.path.join(REPO, "tools", "time_single_game.py")])
@@ -44,7 +44,7 @@ sets = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
 vals = {}
 with open(os.path.join(out, tag + "_pmc.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 --sims 20 "
-            "--no-cpu-baseline --no-single-game (one pass per counter set)\n"
+            "--no-cpu-baseline --no-single-game --no-fp32-compare (one pass per counter set)\n"
             "# FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE under-counts wide coalesced reads "
             "by 2x (MI355X_MICROARCH.md, HBM section)\n")
     for name, ctrs in sets.items():
@@ -59,23 +59,25 @@ with open(os.path.join(out, tag + "_pmc.txt"), "w") as f:
                                   "group by kernel_name, counter_name"):
             vals[(k, cn)] = a
 
-dom = [k for (k, cn) in vals if "k_trunk16" in k]
+c = sqlite3.connect(db)
+row = c.execute("select name, avg(end-start), count(*) from kernels group by name order by sum(end-start) desc limit 1").fetchone()
+dom_name = row[0] if row else None
+dom = [k for (k, cn) in vals if dom_name and k == dom_name]
 if dom:
     k = dom[0]
+    short = k.replace("void ", "").replace("ao::", "").split("(")[0]
     fetch, write = vals.get((k, "FETCH_SIZE")), vals.get((k, "WRITE_SIZE"))
     busy, mfma = vals.get((k, "SQ_BUSY_CYCLES")), vals.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"))
-    tj = {"kernel": "k_trunk16<9,9,1>",
-          "workload": "4096 boards, 4-block/128-ch PVNet, one launch = conv1 + 8 trunk convs + heads",
+    tj = {"kernel": short,
+          "workload": "4096 boards, 4-block/128-ch PVNet, one launch = the trunk convs + heads of the dominant kernel",
           "fetch_size_kib": fetch, "write_size_kib": write, "fetch_correction": 2.0,
           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
           "source": "profiles/%s_pmc.txt (rocprofv3 --pmc, separate passes, MI355X)" % tag}
     # MFMA pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs; the kernel offers
     # 1024 x (duration x 2.4 GHz) SIMD-cycles (duration from the --stats pass of the same build)
-    c = sqlite3.connect(db)
-    row = c.execute("select avg(end-start) from kernels where name like '%k_trunk16%'").fetchone()
-    if row and row[0] and mfma:
-        tj["avg_launch_ns"] = row[0]
-        tj["mfma_busy_fraction"] = mfma / (1024.0 * row[0] * 2.4)
+    if row and row[1] and mfma:
+        tj["avg_launch_ns"] = row[1]
+        tj["mfma_busy_fraction"] = mfma / (1024.0 * row[1] * 2.4)
     tj["sq_valu_mfma_busy_cycles"] = mfma
     tj["sq_busy_cycles"] = busy
     tj["grbm_gui_active"] = vals.get((k, "GRBM_GUI_ACTIVE"))
