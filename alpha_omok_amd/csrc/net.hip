@@ -229,9 +229,7 @@ struct TrunkArgs {
 // fragments of tap row dy are re-loaded for the next step right after their last MFMA.
 // When input row yi is done, output row yi-1 is complete: its epilogue (BN scale/shift, residual,
 // ReLU, store) runs and the window slides (accumulator registers move down one row).
-// OUT16: the epilogue writes the split-fp16 activation layout of k_trunk16h instead of fp32
-// (used for conv1, whose input planes are fp32; never combined with RES).
-template <int BW, int XT, int TPW, bool OUT16 = false>
+template <int BW, int XT, int TPW>
 __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, float4* dst,
                                             const float4* __restrict__ wt, const float4* __restrict__ scp,
                                             const float4* __restrict__ shp, const bool RES, int cqi, int cq_real,
@@ -359,24 +357,7 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
                     // and the compiler only inserts the wait states that protects them from the
                     // next VALU write when soffset is NOT an SGPR. With an SGPR soffset the rows
                     // of boards 12-15 (the last data beat) were overwritten on gfx950.
-                    if (OUT16) {
-                        // couts 4*kq..4*kq+3 of tile ct = halfs (kq&1)*4.. of oct (ct&1)*2 + (kq>>1) of 32-channel block ct>>1
-                        if (xo < BW) {
-                            const float f[4] = {fmaxf(vx, 0.f), fmaxf(vy, 0.f), fmaxf(vz, 0.f), fmaxf(vw, 0.f)};
-                            half4 hh, hl;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                hh[r] = static_cast<_Float16>(f[r]);
-                                hl[r] = static_cast<_Float16>(f[r] - static_cast<float>(hh[r]));
-                            }
-                            const int ct = ct0 + tl;
-                            char* base = reinterpret_cast<char*>(dst) +
-                                         ((((gbase + yo * BW + xo) * (COUT >> 5) + (ct >> 1)) * 2) * 64 +
-                                          ((ct & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
-                            *reinterpret_cast<half4*>(base) = hh;
-                            *reinterpret_cast<half4*>(base + 1024) = hl;
-                        }
-                    } else if (xo < BW)
+                    if (xo < BW)
                         __builtin_amdgcn_raw_buffer_store_b128(o, rs_o, lane_x + orow + (xo * CQO + tl * 4) * GB * 16, 0, 0);
                 }
             }
@@ -572,9 +553,10 @@ struct TrunkHLayer {
 };
 
 struct TrunkHArgs {
+    const float4* in0;  // fp32 plane batch [grp][cell][quad 8][board 16] (conv1 input)
     uint4* bufA;  // conv1 output / ResBlock input-output (split-fp16 layout)
     uint4* bufB;
-    int nlayers;  // trunk convs after conv1: 2 * n_block
+    int nlayers;  // 1 + 2 * n_block, conv1 included
     int CQ, COUT;
     const float *w3, *sc3, *sh3, *wp_t, *bp, *w1_t, *b1, *w2, *b2;
     float* policy;
@@ -597,148 +579,188 @@ __device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
 
-template <int BW, int NC32>
-__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
+// One conv layer of one 16-board group. NCI = 32-channel blocks of the INPUT (NC32 for a trunk layer).
+// FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real),
+// exact in fp16, so it is converted while it is staged, has no low half, and the xl*wh product is dropped.
+template <int BW, int NC32, int NCI, bool FIRST>
+__device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
+                                              int tile, int lane) {
     constexpr int A = BW * BW;
     constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
-    constexpr int NFR = BW * NC32 * 2;       // activation fragments per board row
-    constexpr int NB = NC32 * 3;             // (32-channel block, tap row) slabs per input row
-    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][NFR][64] uint4
-    const int grp = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
+    constexpr int NSP = FIRST ? 1 : 2;       // halves of an input fragment
+    constexpr int NFR = BW * NCI * NSP;      // input fragments per board row
+    constexpr int NB = NCI * 3;              // (32-channel block, tap row) slabs per input row
+    constexpr int NPR = FIRST ? 2 : 3;       // MFMA products per multiply-add
     const int kq = lane >> 4, b = lane & 15;
-    const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first fragment of this group
     const int lane16 = lane * 16;
     // per-lane byte offset of this lane's 4 output channels inside a (cell, 32-channel block) fragment pair
     const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
-
-    for (int l = 0; l < a.nlayers; ++l) {
-        // l even: first conv of a ResBlock (x -> t); l odd: second conv (t -> x, + x in place)
-        const uint4* src = ((l & 1) ? a.bufB : a.bufA) + gfrag * 64;
-        uint4* dst = ((l & 1) ? a.bufA : a.bufB) + gfrag * 64;
-        const bool RES = (l & 1) != 0;
-        const TrunkHLayer L = a.layers[l];
-        const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
-        const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NC32 * NT * 1024u);
-        const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NC32 * NT * 1024u);
-        const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
-        const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
-        // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of
-        // the SIMD computes meanwhile)
-        half8 wA[2][3], wB[2][3];
-        auto load_w = [&](int slab, half8 (&W)[2][3]) {
-            const int c = (slab / 3) % NC32, dy = slab % 3;
+    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+    // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of the
+    // SIMD computes meanwhile)
+    // (conv1 has a single 32-channel block: its 9 x 2 fragments are simply loaded once)
+    half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
+    auto load_w = [&](int slab, half8 (&W)[2][3]) {
+        if (FIRST) return;
+        const int c = (slab / 3) % NCI, dy = slab % 3;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ub = (((dy * 3 + dx) * NC32 + c) * NT + tile) * 1024;
-                W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
-                W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
-            }
-        };
-        f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto epilogue = [&](int yo) {
-#pragma unroll
-            for (int i = 0; i < BW; ++i) {
-                const f32x4 c = acc[0][i];
-                float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z),
-                              fmaf(c[3], sc.w, sh.w)};
-                const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
-                if (RES) {
-                    const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
-                    const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
-                }
-                half4 hh, hl;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(f[r], 0.f);
-                    hh[r] = static_cast<_Float16>(v);
-                    hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
-                }
-                buf_st_h4(hh, rs_dst, out_voff, ob);
-                buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
-            }
-        };
-
-        // stage input row 0 (wave w copies fragments w, w + NT, ...)
-        __syncthreads();  // the previous layer is done with both row buffers
-        for (int f = tile; f < NFR; f += NT)
-            s_x[f * 64 + lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, f * 1024, 0));
-        load_w(0, wA);
-        __syncthreads();
-
-        for (int yi = 0; yi < BW; ++yi) {
-            const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
-            uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
-            const int gn = (yi + 1 < BW ? yi + 1 : yi) * NFR * 1024;   // byte offset of the next row in src
-#pragma unroll
-            for (int slab = 0; slab < NB; ++slab) {
-                const int c = slab / 3, dy = slab % 3;
-                half8 (&w)[2][3] = (slab & 1) ? wB : wA;
-                half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
-                load_w(slab + 1, wn);   // NB is even: the parity carries over from one row to the next
-                if (dy == 1) {
-                    // next input row straight into LDS, a share per block (always-executed slab)
-#pragma unroll
-                    for (int k = 0; k < (NFR / NT + NC32 - 1) / NC32; ++k) {
-                        const int f = tile + NT * (c * ((NFR / NT + NC32 - 1) / NC32) + k);
-                        if (f < NFR)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
-                                                                 16, lane16, gn + f * 1024, 0, 0);
-                    }
-                }
-                const int yo = yi + 1 - dy;
-                if (yo >= 0 && yo < BW) {   // (uniform)
-                    half8 xh = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 0) * 64 + lane]);
-                    half8 xl = __builtin_bit_cast(half8, xs[((0 * NC32 + c) * 2 + 1) * 64 + lane]);
-#pragma unroll
-                    for (int xi = 0; xi < BW; ++xi) {
-                        half8 nh = xh, nl = xl;
-                        if (xi + 1 < BW) {
-                            nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 0) * 64 + lane]);
-                            nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NC32 + c) * 2 + 1) * 64 + lane]);
-                        }
-                        // input cell (yi, xi) feeds output row yo at cells xi-dx+1: xh*wh, xh*wl, xl*wh, ordered so
-                        // that consecutive MFMAs hit different accumulators
-#pragma unroll
-                        for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-                            for (int dx = 0; dx < 3; ++dx) {
-                                const int i = xi - dx + 1;
-                                if (i < 0 || i >= BW) continue;
-                                acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[pr == 1 ? 1 : 0][dx], pr == 2 ? xl : xh,
-                                                                                      acc[2 - dy][i], 0, 0, 0);
-                            }
-                        }
-                        xh = nh;
-                        xl = nl;
-                        // keeps the scheduler from hoisting every LDS read of the slab to its top (72 registers)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (yi >= 1) epilogue(yi - 1);
-#pragma unroll
-            for (int i = 0; i < BW; ++i) {
-                acc[0][i] = acc[1][i];
-                acc[1][i] = acc[2][i];
-                acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+            W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
         }
-        epilogue(BW - 1);
-        // layer boundary inside the workgroup (see k_trunk16)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    if (FIRST) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
+            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+        }
+    }
+    // conv1: one fragment = channels 8*kq .. 8*kq+7 of (cell, board b) = two float4 quads of the fp32 batch
+    auto load_planes = [&](int cell) -> half8 {
+        const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
+        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
+        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
+        half8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = static_cast<_Float16>(__uint_as_float(q0[k]));
+            h[4 + k] = static_cast<_Float16>(__uint_as_float(q1[k]));
+        }
+        return h;
+    };
+    f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto epilogue = [&](int yo) {
+#pragma unroll
+        for (int i = 0; i < BW; ++i) {
+            const f32x4 c = acc[0][i];
+            float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+            const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+            if (RES) {
+                const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
+                const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+            }
+            half4 hh, hl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(f[r], 0.f);
+                hh[r] = static_cast<_Float16>(v);
+                hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+            }
+            buf_st_h4(hh, rs_dst, out_voff, ob);
+            buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+        }
+    };
+
+    // stage input row 0 (wave w copies fragments w, w + NT, ...)
+    __syncthreads();  // the previous layer is done with both row buffers
+    for (int f = tile; f < NFR; f += NT) {
+        if (FIRST) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f));
+        else s_x[f * 64 + lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, f * 1024, 0));
+    }
+    load_w(0, wA);
+    __syncthreads();
+
+    for (int yi = 0; yi < BW; ++yi) {
+        const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
+        uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
+        const int yn = yi + 1 < BW ? yi + 1 : yi;                               // next input row (clamped)
+#pragma unroll
+        for (int slab = 0; slab < NB; ++slab) {
+            const int c = slab / 3, dy = slab % 3;
+            // (NB is even for the trunk layers: the buffer parity carries over from one row to the next)
+            half8 (&w)[2][3] = (slab & 1) ? wB : wA;
+            half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
+            load_w(slab + 1, wn);
+            if (dy == 1) {
+                // next input row into LDS, a share per block (always-executed slab)
+#pragma unroll
+                for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
+                    const int f = tile + NT * (c * ((NFR / NT + NCI) / NCI) + k);
+                    if (f < NFR) {
+                        if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + f));
+                        else
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
+                                                                     16, lane16, (yn * NFR + f) * 1024, 0, 0);
+                    }
+                }
+            }
+            const int yo = yi + 1 - dy;
+            if (yo >= 0 && yo < BW) {   // (uniform)
+                half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
+                half8 xl = FIRST ? xh : __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+#pragma unroll
+                for (int xi = 0; xi < BW; ++xi) {
+                    half8 nh = xh, nl = xl;
+                    if (xi + 1 < BW) {
+                        nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 0) * 64 + lane]);
+                        if (!FIRST) nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                    }
+                    // input cell (yi, xi) feeds output row yo at cells xi-dx+1: xh*wh, xh*wl, xl*wh, ordered so that
+                    // consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int i = xi - dx + 1;
+                            if (i < 0 || i >= BW) continue;
+                            const half8 wv = FIRST ? wres[pr == 1 ? 1 : 0][FIRST ? dy * 3 + dx : 0] : w[pr == 1 ? 1 : 0][dx];
+                            acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, pr == 2 ? xl : xh, acc[2 - dy][i], 0, 0, 0);
+                        }
+                    }
+                    xh = nh;
+                    xl = nl;
+                    // keeps the scheduler from hoisting every LDS read of the slab to its top (72 registers)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (yi >= 1) epilogue(yi - 1);
+#pragma unroll
+        for (int i = 0; i < BW; ++i) {
+            acc[0][i] = acc[1][i];
+            acc[1][i] = acc[2][i];
+            acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    epilogue(BW - 1);
+    // layer boundary inside the workgroup (see k_trunk16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <int BW, int NC32>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
+    constexpr int A = BW * BW;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][row fragments][64] uint4
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
+    const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first activation fragment of this group
+    uint4* bufA = a.bufA + gfrag * 64;
+    uint4* bufB = a.bufB + gfrag * 64;
+    // conv1: fp32 planes -> x
+    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane);
+    for (int l = 1; l < a.nlayers; ++l) {
+        // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
+        const bool second = (l & 1) == 0;
+        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane);
     }
     trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
 }
@@ -780,7 +802,7 @@ struct LayerArgs {
     int res, cqi, cq_real, COUT, nch;
 };
 
-template <int BW, int XT, bool OUT16 = false>
+template <int BW, int XT>
 __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
     constexpr int A = BW * BW;
     const int grp = blockIdx.x / a.nch;
@@ -790,8 +812,8 @@ __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
     const int ye = yb + base + (c < extra ? 1 : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-    trunk_layer<BW, XT, 1, OUT16>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real,
-                                  a.COUT, static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
+    trunk_layer<BW, XT, 1>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real, a.COUT,
+                           static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
 }
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
@@ -995,7 +1017,7 @@ static void timer_end(ao_net* n, int idx, hipStream_t s) {
 // mode 5 (k_trunk16h) is built for 128 planes, boards up to 9x9 (one input row of a 16-board group in both
 // halves = 72 KB, two of them in LDS) and at least one ResBlock
 static bool h16_supported(const ao_net* n) {
-    return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 2 * n->nb <= ao::kMaxTrunkLayers;
+    return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
 
 namespace ao {
@@ -1179,19 +1201,13 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         NET_HIP(n, hipGetLastError());
         return 0;
     } else if (group == 16 && mode == 5) {
-        // split-fp16 resident trunk: conv1 (fp32 planes in, K = 32) runs on the fp32 window kernel and writes
-        // the split layout; one resident launch then carries every group through the ResBlocks and the heads
-        LayerArgs c1;
-        c1.src = reinterpret_cast<const float4*>(in_il);
-        c1.dst = reinterpret_cast<float4*>(n->act_x);
-        c1.layer.w = reinterpret_cast<const float4*>(n->conv0_w16);
-        c1.layer.sc = reinterpret_cast<const float4*>(n->conv_sc[0]);
-        c1.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[0]);
-        c1.res = 0; c1.cqi = n->nchq16; c1.cq_real = (n->C + 3) / 4; c1.COUT = n->planes; c1.nch = 1;
+        // split-fp16 resident trunk: one launch carries every 16-board group through conv1 (fp32 planes converted
+        // while they are staged), the ResBlocks and the heads
         TrunkHArgs a;
+        a.in0 = reinterpret_cast<const float4*>(in_il);
         a.bufA = reinterpret_cast<uint4*>(n->act_x);
         a.bufB = reinterpret_cast<uint4*>(n->act_t);
-        a.nlayers = 2 * n->nb;
+        a.nlayers = 1 + 2 * n->nb;
         a.CQ = n->CQ;
         a.COUT = n->planes;
         a.w3 = n->head_w3; a.sc3 = n->head_sc3; a.sh3 = n->head_sh3;
@@ -1202,7 +1218,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layers[l].wh = n->convh_wh[l];
             a.layers[l].wl = n->convh_wl[l];
             a.layers[l].sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
-            a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l + 1]);
+            a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
         }
         static bool attr_done[16] = {};
         const int idx = n->timing ? timer_begin(n, s) : 0;
@@ -1215,7 +1231,6 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
             attr_done[W] = true;                                                                             \
         }                                                                                                    \
-        hipLaunchKernelGGL((k_layer16<W, W, true>), dim3(groups), dim3(512), 0, s, c1);                      \
         hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                         \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
@@ -1449,18 +1464,30 @@ int ao_net_finalize(ao_net* n) {
         if (add_conv(pre + ".conv2.weight", pre + ".bn2", P, n->CQ)) return 1;
     }
     if (h16_supported(n)) {
-        for (int l = 1; l <= 2 * n->nb; ++l) {
-            const std::string pre = "layers." + std::to_string((l - 1) / 2);
-            const std::string cname = pre + ((l & 1) ? ".conv1.weight" : ".conv2.weight");
-            const std::string bname = pre + ((l & 1) ? ".bn1" : ".bn2");
-            const std::vector<float>* w;
-            if (get_param(n, cname, static_cast<size_t>(P) * P * 9, &w)) return 1;
+        for (int l = 0; l <= 2 * n->nb; ++l) {
+            const std::string pre = "layers." + std::to_string(l ? (l - 1) / 2 : 0);
+            const std::string cname = l == 0 ? std::string("conv1.weight") : pre + ((l & 1) ? ".conv1.weight" : ".conv2.weight");
+            const std::string bname = l == 0 ? std::string("bn1") : pre + ((l & 1) ? ".bn1" : ".bn2");
+            const int cin = l == 0 ? n->C : P;
+            const std::vector<float>* w0;
+            if (get_param(n, cname, static_cast<size_t>(P) * cin * 9, &w0)) return 1;
+            // conv1: input channels zero-padded to one 32-channel block
+            std::vector<float> wpad;
+            const std::vector<float>* w = w0;
+            const int cinp = l == 0 ? 32 : P;
+            if (l == 0) {
+                wpad.assign(static_cast<size_t>(P) * 32 * 9, 0.f);
+                for (int co = 0; co < P; ++co)
+                    for (int ci = 0; ci < n->C; ++ci)
+                        for (int t = 0; t < 9; ++t) wpad[(static_cast<size_t>(co) * 32 + ci) * 9 + t] = (*w0)[(static_cast<size_t>(co) * n->C + ci) * 9 + t];
+                w = &wpad;
+            }
             float mx = 0.f;
             for (float v : *w) mx = std::max(mx, std::fabs(v));
             // power-of-two pre-scale: largest |w| lands in [4, 8), so the low halves are normal fp16 numbers
             const int sft = (mx > 0.f && std::isfinite(mx)) ? 2 - static_cast<int>(std::floor(std::log2(mx))) : 0;
             std::vector<uint16_t> hi, lo;
-            pack_conv_h(*w, P, P, sft, &hi, &lo);
+            pack_conv_h(*w, P, cinp, sft, &hi, &lo);
             std::vector<float> sc, sh;
             if (fold_bn(n, bname, P, &sc, &sh)) return 1;
             for (float& v : sc) v = std::ldexp(v, -sft);
@@ -1567,7 +1594,7 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
         nm = "k_layer16<" + std::to_string(n->B) + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
     } else if (group == 16 && ao::pick_mode_public(n, boards) == 5) {
-        nm = "k_trunk16h<" + std::to_string(n->B) + "> (conv1 fp32 + " + std::to_string(2 * n->nb) +
+        nm = "k_trunk16h<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
              " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), one resident launch)";
         f = conv1 + 2.0 * n->nb * conv;
     } else if (group == 16) {
