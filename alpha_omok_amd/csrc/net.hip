@@ -655,7 +655,9 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             half4 hh, hl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(f[r], 0.f);
+                // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
+                // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN
+                const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
                 hh[r] = static_cast<_Float16>(v);
                 hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
             }
