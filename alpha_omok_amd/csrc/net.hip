@@ -747,6 +747,197 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// The same layer for ONE (row chunk [yb, ye), column tile x0 .. x0+XT-1) of a group: the per-layer form for
+// batches too small to give every CU a whole group (k_layer16h: one launch per conv, workgroup = group x row
+// chunk x column tile) and for boards whose rows do not fit LDS (15 x 15: XT = 5, a staged row is the tile
+// plus one halo column on each side = 7 cells = 56 KB, two of them 112 KB). Halo columns that fall off the
+// board are staged as zeros, so the MFMA stream needs no per-column conditions; halo rows are handled by the
+// slab conditions (uniform per row) exactly as in the fp32 row-chunk kernel.
+template <int BW, int XT, int NC32, int NCI, bool FIRST>
+__device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES,
+                                                   uint4* s_x, int tile, int lane, int x0, int yb, int ye) {
+    constexpr int A = BW * BW;
+    constexpr bool HALO = XT < BW;
+    constexpr int NX = HALO ? XT + 2 : XT;   // staged input cells per row; staged cell j = board column x0 - 1 + j (HALO) or j
+    constexpr int NT = NC32 * 2;
+    constexpr int NSP = FIRST ? 1 : 2;
+    constexpr int NFR = NX * NCI * NSP;
+    constexpr int NB = NCI * 3;
+    constexpr int NPR = FIRST ? 2 : 3;
+    const int kq = lane >> 4, b = lane & 15;
+    const int lane16 = lane * 16;
+    const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+    half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
+    auto load_w = [&](int slab, half8 (&W)[2][3]) {
+        if (FIRST) return;
+        const int c = (slab / 3) % NCI, dy = slab % 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+            W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+        }
+    };
+    if (FIRST) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
+            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+        }
+    }
+    auto load_planes = [&](int cell) -> half8 {
+        const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
+        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
+        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
+        half8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = static_cast<_Float16>(__uint_as_float(q0[k]));
+            h[4 + k] = static_cast<_Float16>(__uint_as_float(q1[k]));
+        }
+        return h;
+    };
+    // stage this wave's share of input row y into row buffer `xb`
+    auto stage = [&](int y, uint4* xb) {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;   // staged fragment: (cell j, block c, half)
+            if (f < NFR) {
+                const int j = f / (NCI * NSP), rest = f - j * (NCI * NSP);
+                const int xin = HALO ? x0 - 1 + j : j;
+                if (xin < 0 || xin >= BW) {
+                    xb[f * 64 + lane] = make_uint4(0, 0, 0, 0);   // halo column outside the board
+                } else if (FIRST) {
+                    xb[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(y * BW + xin));
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + f * 64), 16,
+                                                             lane16, ((y * BW + xin) * NCI * 2 + rest) * 1024, 0, 0);
+                }
+            }
+        }
+    };
+    f32x4 acc[3][XT];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < XT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto epilogue = [&](int yo) {
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            if (x0 + i >= BW) continue;   // (only when XT does not divide BW; uniform)
+            const f32x4 c = acc[0][i];
+            float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+            const int ob = (((yo * BW + x0 + i) * NC32 + (tile >> 1)) * 2) * 1024;
+            if (RES) {
+                const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
+                const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+            }
+            half4 hh, hl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
+                hh[r] = static_cast<_Float16>(v);
+                hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+            }
+            buf_st_h4(hh, rs_dst, out_voff, ob);
+            buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+        }
+    };
+
+    const int y0 = yb > 0 ? yb - 1 : 0;          // input rows that feed output rows [yb, ye)
+    const int y1 = ye < BW ? ye : BW - 1;
+    stage(y0, s_x);
+    load_w(0, wA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int yi = y0; yi <= y1; ++yi) {
+        const int par = (yi - y0) & 1;
+        const uint4* xs = s_x + static_cast<size_t>(par) * NFR * 64;
+        uint4* xn = s_x + static_cast<size_t>(par ^ 1) * NFR * 64;
+#pragma unroll
+        for (int slab = 0; slab < NB; ++slab) {
+            const int c = slab / 3, dy = slab % 3;
+            half8 (&w)[2][3] = (slab & 1) ? wB : wA;
+            half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
+            load_w(slab + 1, wn);
+            if (slab == 1 && yi < y1) stage(yi + 1, xn);
+            const int yo = yi + 1 - dy;
+            if (yo >= yb && yo < ye) {   // (uniform)
+                half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
+                half8 xl = FIRST ? xh : __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    half8 nh = xh, nl = xl;
+                    if (j + 1 < NX) {
+                        nh = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + 0) * 64 + lane]);
+                        if (!FIRST) nl = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int i = HALO ? j - dx : j - dx + 1;   // output cell of the tile fed through tap column dx
+                            if (i < 0 || i >= XT) continue;
+                            const half8 wv = FIRST ? wres[pr == 1 ? 1 : 0][FIRST ? dy * 3 + dx : 0] : w[pr == 1 ? 1 : 0][dx];
+                            acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, pr == 2 ? xl : xh, acc[2 - dy][i], 0, 0, 0);
+                        }
+                    }
+                    xh = nh;
+                    xl = nl;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (yi - 1 >= yb) epilogue(yi - 1);
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            acc[0][i] = acc[1][i];
+            acc[1][i] = acc[2][i];
+            acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (ye == BW) epilogue(BW - 1);
+}
+
+struct LayerHArgs {
+    const void* src;   // fp32 plane batch (conv1) or split-fp16 activations
+    uint4* dst;
+    TrunkHLayer layer;
+    int res, nch;
+};
+
+template <int BW, int XT, int NC32, bool FIRST>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
+    constexpr int A = BW * BW;
+    constexpr int NXT = (BW + XT - 1) / XT;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];
+    const int xt = blockIdx.x % NXT;
+    const int rest = blockIdx.x / NXT;
+    const int grp = rest / a.nch, ch = rest - grp * a.nch;
+    const int base = BW / a.nch, extra = BW % a.nch;
+    const int yb = ch * base + (ch < extra ? ch : extra);
+    const int ye = yb + base + (ch < extra ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    uint4* dst = a.dst + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
+    if (FIRST) {
+        trunk_h_layer_tile<BW, XT, NC32, 1, true>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
+                                                  false, s_x, tile, lane, xt * XT, yb, ye);
+    } else {
+        trunk_h_layer_tile<BW, XT, NC32, NC32, false>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
+                                                      a.layer, a.res != 0, s_x, tile, lane, xt * XT, yb, ye);
+    }
+}
+
 template <int BW, int NC32>
 __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     constexpr int A = BW * BW;
@@ -820,6 +1011,8 @@ __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.
 // hbuf[board][3][A]: channel 0,1 = policy head, 2 = value head.
+// H16: `in` is in the split-fp16 layout of the k_trunk16h / k_layer16h kernels (GB = 16)
+template <bool H16>
 __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in, const float* __restrict__ w3,
                                                    const float* __restrict__ sc3, const float* __restrict__ sh3,
                                                    float* __restrict__ hbuf, int A, int CQ, int GB) {
@@ -836,7 +1029,18 @@ __global__ __launch_bounds__(256) void k_head_conv(const float4* __restrict__ in
     const float4* xp = in + ((static_cast<size_t>(grp) * A + pos) * CQ) * GB + b;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int cq = 0; cq < CQ; ++cq) {
-        const float4 x = xp[static_cast<size_t>(cq) * GB];
+        float4 x;
+        if (H16) {
+            const char* base = reinterpret_cast<const char*>(in) +
+                               ((((static_cast<size_t>(grp) * A + pos) * (CQ >> 3) + (cq >> 3)) * 2) * 64 + ((cq & 7) >> 1) * 16 + b) * 16 +
+                               (cq & 1) * 8;
+            const half4 hh = *reinterpret_cast<const half4*>(base);
+            const half4 hl = *reinterpret_cast<const half4*>(base + 1024);
+            x = make_float4(static_cast<float>(hh[0]) + static_cast<float>(hl[0]), static_cast<float>(hh[1]) + static_cast<float>(hl[1]),
+                            static_cast<float>(hh[2]) + static_cast<float>(hl[2]), static_cast<float>(hh[3]) + static_cast<float>(hl[3]));
+        } else {
+            x = xp[static_cast<size_t>(cq) * GB];
+        }
         const float* w0 = s_w + 4 * cq;
         const float* w1 = s_w + planes + 4 * cq;
         const float* w2 = s_w + 2 * planes + 4 * cq;
@@ -1016,10 +1220,10 @@ static void timer_end(ao_net* n, int idx, hipStream_t s) {
     ++n->ring_count;
 }
 
-// mode 5 (k_trunk16h) is built for 128 planes, boards up to 9x9 (one input row of a 16-board group in both
-// halves = 72 KB, two of them in LDS) and at least one ResBlock
+// mode 5 (split-fp16 MFMA trunk: k_trunk16h resident for boards up to 9x9 with >= 192 groups, k_layer16h per
+// layer otherwise) is built for 128 planes and at least one ResBlock
 static bool h16_supported(const ao_net* n) {
-    return n->planes == 128 && n->B <= 9 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
+    return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
 
 namespace ao {
@@ -1152,6 +1356,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
     int group = 32, nchq = 0, nch = 1;
+    bool heads_h16 = false;   // the separate head kernels read the split-fp16 layout
     net_plan(n, boards, &group, &nchq);
     const int mode = pick_mode(n, boards, &nch);
     const int groups = (boards + group - 1) / group;
@@ -1202,6 +1407,60 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                            reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
         return 0;
+    } else if (group == 16 && mode == 5 && !(n->B <= 9 && groups >= 192)) {
+        // split-fp16 trunk, one launch per conv: workgroup = (16-board group, row chunk, column tile). For batches
+        // that cannot give every CU a whole group, and for boards wider than 9 (a staged row must fit LDS twice)
+        const int nxt = n->B <= 9 ? 1 : (n->B + 4) / 5;
+        int nchh = 1;
+        {
+            long best = -1;
+            for (int c = 1; c <= n->B; ++c) {
+                const long rounds = (static_cast<long>(groups) * c * nxt + n->num_cu - 1) / n->num_cu;
+                const long cost = rounds * ((n->B + c - 1) / c + 1);   // rows of a chunk + its halo rows' staging
+                if (best < 0 || cost < best) { best = cost; nchh = c; }
+            }
+        }
+        static bool attr_l[16][2] = {};
+        auto layer = [&](int l) -> int {
+            LayerHArgs a;
+            a.src = l == 0 ? static_cast<const void*>(in_il) : static_cast<const void*>((l & 1) ? n->act_x : n->act_t);
+            a.dst = reinterpret_cast<uint4*>((l == 0 || !(l & 1)) ? n->act_x : n->act_t);
+            a.layer.wh = n->convh_wh[l];
+            a.layer.wl = n->convh_wl[l];
+            a.layer.sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
+            a.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+            a.res = (l > 0 && !(l & 1)) ? 1 : 0;
+            a.nch = nchh;
+            const dim3 grid(groups * nchh * nxt), block(512);
+            const bool timed = n->timing && l > 0;
+            const int idx = timed ? timer_begin(n, s) : 0;
+            switch (n->B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W: {                                                                                                          \
+        constexpr int XT_ = (W <= 9) ? W : 5;                                                                          \
+        constexpr int NX_ = (XT_ < W) ? XT_ + 2 : XT_;                                                                 \
+        constexpr size_t lds_ = static_cast<size_t>(2) * NX_ * 4 * 2 * 1024;                                           \
+        if (!attr_l[W][0]) {                                                                                           \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, false>),               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, true>),                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            attr_l[W][0] = true;                                                                                       \
+        }                                                                                                              \
+        if (l == 0) hipLaunchKernelGGL((k_layer16h<W, XT_, 4, true>), grid, block, lds_, s, a);                       \
+        else hipLaunchKernelGGL((k_layer16h<W, XT_, 4, false>), grid, block, lds_, s, a);                             \
+    } break;
+                AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+                AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+            }
+            if (timed) timer_end(n, idx, s);
+            return 0;
+        };
+        for (int l = 0; l <= 2 * n->nb; ++l)
+            if (layer(l)) return 1;
+        NET_HIP(n, hipGetLastError());
+        heads_h16 = true;   // k_head_conv<true> / k_head_fc below
     } else if (group == 16 && mode == 5) {
         // split-fp16 resident trunk: one launch carries every 16-board group through conv1 (fp32 planes converted
         // while they are staged), the ResBlocks and the heads
@@ -1308,9 +1567,14 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     }
     const int ppb = 256 / group;
     const int nchunk = (n->A + ppb - 1) / ppb;
-    hipLaunchKernelGGL(k_head_conv, dim3(groups * nchunk), dim3(256), 3 * n->planes * sizeof(float), s,
-                       reinterpret_cast<const float4*>(n->act_x), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf,
-                       n->A, n->CQ, group);
+    if (heads_h16)
+        hipLaunchKernelGGL(k_head_conv<true>, dim3(groups * nchunk), dim3(256), 3 * n->planes * sizeof(float), s,
+                           reinterpret_cast<const float4*>(n->act_x), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf,
+                           n->A, n->CQ, group);
+    else
+        hipLaunchKernelGGL(k_head_conv<false>, dim3(groups * nchunk), dim3(256), 3 * n->planes * sizeof(float), s,
+                           reinterpret_cast<const float4*>(n->act_x), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf,
+                           n->A, n->CQ, group);
     const size_t lds = (static_cast<size_t>(4) * n->A + n->planes + 8) * sizeof(float);
     hipLaunchKernelGGL(k_head_fc, dim3(groups * group), dim3(256), lds, s, n->hbuf, n->wp_t, n->bp, n->w1_t,
                        n->b1, n->w2, n->b2, policy, value, n->A, n->planes);
@@ -1365,7 +1629,7 @@ int ao_net_set_mode(ao_net* n, int mode) {
     if (mode < 0 || mode > 5)
         return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board), 4 (row-chunked) or 5 (split-fp16 trunk)");
     if (mode == 5 && !h16_supported(n))
-        return n->fail("mode 5 (split-fp16 resident trunk) needs 128 planes, a board of at most 9x9 and at least one ResBlock");
+        return n->fail("mode 5 (split-fp16 MFMA trunk) needs 128 planes and at least one ResBlock");
     n->mode = mode;
     return 0;
 }
