@@ -1245,11 +1245,14 @@ int pick_mode_public(const ao_net* n, int boards);
 static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     int mode = n->mode;
     const int g16 = (boards + 15) / 16;
-    // measured cross-over of the per-board path and the row-chunked layers: 128 boards 529 vs 676 us,
-    // 256 boards 979 vs 676 us per simulation (9x9, 4 blocks)
-    // big batches: the group-resident trunk, on split-fp16 MFMAs where that kernel exists (2.6x the fp32-MFMA
-    // trunk at the same accuracy), else on fp32 MFMAs
-    if (mode == 0) mode = (static_cast<long>(boards) * n->A <= 13000) ? 3 : (g16 >= 192 ? (h16_supported(n) ? 5 : 2) : 4);
+    // measured cross-overs (us per simulation, 9x9, 4 blocks): per-board path vs fp32 row-chunked layers 529 / 676
+    // at 128 boards and 979 / 676 at 256; per-board path vs split-fp16 layers 174 / 246 at 32 boards and 307 / 258
+    // at 64 (15x15, 10 blocks: 518 / 501 at 16 boards)
+    if (mode == 0) {
+        const long cells = static_cast<long>(boards) * n->A;
+        if (h16_supported(n)) mode = cells <= 3800 ? 3 : 5;
+        else mode = cells <= 13000 ? 3 : (g16 >= 192 ? 2 : 4);
+    }
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
     int nch = 1;
     if (mode == 4) {
@@ -1858,6 +1861,10 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
         f = conv;
  } else if (group == 16 && ao::pick_mode_public(n, boards) == 4) {
         nm = "k_layer16<" + std::to_string(n->B) + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
+        f = conv;
+    } else if (group == 16 && ao::pick_mode_public(n, boards) == 5 && !(n->B <= 9 && (boards + 15) / 16 >= 192)) {
+        nm = "k_layer16h<" + std::to_string(n->B) + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
+             "16-board groups x row chunks x column tiles)";
         f = conv;
     } else if (group == 16 && ao::pick_mode_public(n, boards) == 5) {
         nm = "k_trunk16h<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +

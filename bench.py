@@ -222,10 +222,10 @@ def main():
         except Exception:
             traffic = None
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
-        split16 = kname.startswith("k_trunk16h")
+        split16 = kname.startswith("k_trunk16h") or kname.startswith("k_layer16h")
         peak = PEAK_F16_MFMA_TFLOPS if split16 else PEAK_F32_MFMA_TFLOPS
         out = {
-            "metric": "self-play move-decisions/sec (9x9, 400 sims/move)",
+            "metric": "self-play move-decisions/sec (%dx%d, %d sims/move)" % (B, B, S),
             "value": value,
             "unit": "move-decisions/s",
             "n_gpus": world,
@@ -238,8 +238,11 @@ def main():
             "dtype": "f32 (fp16x2-split MFMA operands, 3 products per multiply-add, f32 accumulate)" if split16 else "f32",
             "data": "synthetic (self-play from the empty board, random-init weights, per-game seeds)",
             "config": {
-                "workload": "BASELINE configs[2]: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "
-                            "leaf batch %d, random-init %d-block/%d-ch PVNet" % (B, B, G, S, G, args.blocks, args.planes),
+                "workload": "%s: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "
+                            "leaf batch %d, random-init %d-block/%d-ch PVNet" % (
+                                "BASELINE configs[2]" if (B, G, S, args.blocks) == (9, 4096, 400, 4) else
+                                "BASELINE configs[4] per-GPU shape" if (B, G, S, args.blocks) == (15, 1024, 800, 10) else
+                                "custom shape", B, B, G, S, G, args.blocks, args.planes),
                 "games_per_gpu": G, "sims": S, "board": B, "n_block": args.blocks, "planes": args.planes,
                 "parallelism": "games sharded over %d GPU(s), no data-path collective" % world,
                 "mean_select_depth": counters["levels"] / sims_total,

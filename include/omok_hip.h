@@ -143,8 +143,10 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
  * group-resident trunk with the fp32 contraction carried by fp16 MFMAs: every operand is split in
  * two halves (x = xh + xl) and x*w = xh*wh + xh*wl + xl*wh with fp32 accumulation (the dropped
  * xl*wl term is <= 2^-22 of a product; measured error against an fp64 evaluation equals the fp32
- * path's; activations are clamped to the fp16 range, 65504). Mode 5 needs 128 planes, a board of
- * at most 9x9 and at least one ResBlock; it is what mode 0 picks for >= 3072 boards on such a net. */
+ * path's; activations are clamped to the fp16 range, 65504). Mode 5 needs 128 planes and at least one
+ * ResBlock; it runs as one resident launch (boards up to 9x9, >= 3072 boards) or as one launch per conv
+ * over (16-board group x row chunk x column tile) (any board up to 15x15, smaller batches), and is
+ * what mode 0 picks on such a net for batches of more than ~3800 cells (47 9x9 boards). */
 int  ao_net_set_mode(ao_net *n, int mode);
 /* total device time (ms) and launch count of the dominant trunk kernel since the last call
  * (HIP events on the launch stream); used by bench.py's roofline. */
