@@ -640,29 +640,46 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Output row in two batches of cells: all residual loads of a batch are issued before the first is used
+    // (written cell by cell the compiler produced load, wait, store, load, wait-for-everything ...: nine serial
+    // memory round trips per row, 3.8 us; the registers of the X fragments are free here)
     auto epilogue = [&](int yo) {
+        constexpr int HB = (BW + 1) / 2;
 #pragma unroll
-        for (int i = 0; i < BW; ++i) {
-            const f32x4 c = acc[0][i];
-            float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
-            const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+        for (int i0 = 0; i0 < BW; i0 += HB) {
+            half4 rh[HB], rl[HB];
             if (RES) {
-                const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
-                const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+                for (int k = 0; k < HB; ++k) {
+                    const int i = i0 + k < BW ? i0 + k : BW - 1;
+                    const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                    rh[k] = buf_ld_h4(rs_dst, out_voff, ob);
+                    rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+                }
             }
-            half4 hh, hl;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
-                // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN
-                const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
-                hh[r] = static_cast<_Float16>(v);
-                hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+            for (int k = 0; k < HB; ++k) {
+                const int i = i0 + k;
+                if (i >= BW) continue;
+                const f32x4 c = acc[0][i];
+                float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+                const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
+                }
+                half4 hh, hl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
+                    // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN
+                    const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
+                    hh[r] = static_cast<_Float16>(v);
+                    hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+                }
+                buf_st_h4(hh, rs_dst, out_voff, ob);
+                buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
             }
-            buf_st_h4(hh, rs_dst, out_voff, ob);
-            buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
         }
     };
 
@@ -828,6 +845,17 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
 #pragma unroll
         for (int i = 0; i < XT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto epilogue = [&](int yo) {
+        // all residual loads of the row first (see trunk_h_layer)
+        half4 rh[XT], rl[XT];
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) {
+                const int xo = x0 + i < BW ? x0 + i : BW - 1;
+                const int ob = (((yo * BW + xo) * NC32 + (tile >> 1)) * 2) * 1024;
+                rh[i] = buf_ld_h4(rs_dst, out_voff, ob);
+                rl[i] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             if (x0 + i >= BW) continue;   // (only when XT does not divide BW; uniform)
@@ -835,10 +863,8 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
             const int ob = (((yo * BW + x0 + i) * NC32 + (tile >> 1)) * 2) * 1024;
             if (RES) {
-                const half4 rh = buf_ld_h4(rs_dst, out_voff, ob);
-                const half4 rl = buf_ld_h4(rs_dst, out_voff, ob + 1024);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[r]) + static_cast<float>(rl[r]);
+                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[i][r]) + static_cast<float>(rl[i][r]);
             }
             half4 hh, hl;
 #pragma unroll
