@@ -52,6 +52,7 @@ struct ao_engine {
     uint8_t* d_active = nullptr; int8_t* d_tau = nullptr; int32_t* d_extra = nullptr;
     int32_t* d_status = nullptr; uint8_t* d_mask = nullptr;
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
+    size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
     std::vector<std::vector<int32_t>> moves;
     std::vector<int32_t> status;     // AO_ROOT_*
@@ -148,6 +149,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
     p.nchq = (((c.inplanes + 3) / 4) + 7) & ~7;  // worst case of the network's input layouts (net_plan)
+    p.nchq_live = p.nchq;
     p.il_group = ao::kGroup;
     p.c_puct = c.c_puct;
 
@@ -174,7 +176,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     if (dev_alloc(e, &il, static_cast<size_t>(Gp) * A * p.nchq * 4) ||
         dev_alloc(e, &e->d_policy, static_cast<size_t>(Gp) * A) || dev_alloc(e, &e->d_value, Gp))
         return 1;
-    AO_HIP(e, hipMemsetAsync(il, 0, static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float), e->stream));
+    e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
+    AO_HIP(e, hipMemsetAsync(il, 0, e->il_bytes, e->stream));
     p.batch_il = il;
     p.tau = e->d_tau;
     p.active = e->d_active;
@@ -406,6 +409,8 @@ int ao_collect_leaves(ao_engine* e, float* dev_planes_nchw) {
     AO_HIP(e, hipSetDevice(e->cfg.device));
     ao::TreeParams p = e->tp;
     p.batch_nchw = dev_planes_nchw;
+    if (dev_planes_nchw) p.batch_il = nullptr;   // an external evaluator only needs the NCHW planes
+    else e->il_group_zeroed = -1;                // full-width write in whatever layout was planned last
     ao::launch_select(p, e->stream);
     AO_HIP(e, hipGetLastError());
     return 0;
@@ -501,6 +506,14 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
     // the network announces the interleaved input layout it wants for a batch of G boards
     ao::net_plan(net, e->G, &e->tp.il_group, &e->tp.nchq);
+    // The padding channels of the input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
+    // encoder only writes the quads that hold planes (16 B per lane at a 2 KB stride are partial-line writes --
+    // rocprof showed 152 MB of HBM writes per launch for a 42 MB batch). A change of layout re-zeroes the buffer.
+    if (e->il_group_zeroed != e->tp.il_group || e->il_nchq_zeroed != e->tp.nchq) {
+        AO_HIP(e, hipMemsetAsync(e->tp.batch_il, 0, e->il_bytes, e->stream));
+        e->il_group_zeroed = e->tp.il_group;
+        e->il_nchq_zeroed = e->tp.nchq;
+    }
     if (ao_begin_move(e, active)) return 1;
     // select | net | expand+select | net | ... | expand(+idle select): one launch fewer per simulation
     // than the step-wise protocol, same device code (tree_device.hpp).
@@ -508,6 +521,7 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     p.batch_nchw = nullptr;
     p.policy = e->d_policy;
     p.value = e->d_value;
+    p.nchq_live = (e->cfg.inplanes + 3) / 4;
     auto one_sim = [&]() -> int {
         if (ao::net_forward_il(net, p.batch_il, e->G, e->d_policy, e->d_value, e->stream))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));

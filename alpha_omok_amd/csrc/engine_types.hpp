@@ -50,6 +50,7 @@ enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
 struct TreeParams {
     int B, A, Ap, C, win_mark, G, cap, maxd, noise;
     int nchq;  // channel quads of the interleaved input batch: ceil(C/4) rounded up to even
+    int nchq_live;  // quads the plane encoder writes: nchq, or ceil(C/4) when the padding quads are known to be zero
     double c_puct;
     // arena
     int32_t* N; float* W; float* Q; double* P; int32_t* CH; uint8_t* ACT; Pos* meta;

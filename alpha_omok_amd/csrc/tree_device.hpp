@@ -257,7 +257,7 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
         if (p.batch_il) {
             const size_t grp = static_cast<size_t>(g / p.il_group);
             const int b = g % p.il_group;
-            for (int cq = 0; cq < p.nchq; ++cq) {
+            for (int cq = 0; cq < p.nchq_live; ++cq) {
                 const float4 v4 = make_float4(plane(4 * cq), plane(4 * cq + 1), plane(4 * cq + 2), plane(4 * cq + 3));
                 float4* dst = reinterpret_cast<float4*>(p.batch_il) +
                               (((grp * p.A + cell) * p.nchq + cq) * p.il_group + b);
