@@ -580,17 +580,18 @@ __device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int
 }
 
 // One conv layer of one 16-board group. NCI = 32-channel blocks of the INPUT (NC32 for a trunk layer).
-// FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real),
-// exact in fp16, so it is converted while it is staged, has no low half, and the xl*wh product is dropped.
+// FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real); it
+// is split into its two halves while it is staged (the engine's planes are 0/1 and have a zero low half, but
+// ao_net_forward accepts any float planes).
 template <int BW, int NC32, int NCI, bool FIRST>
 __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
                                               int tile, int lane) {
     constexpr int A = BW * BW;
     constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
-    constexpr int NSP = FIRST ? 1 : 2;       // halves of an input fragment
+    constexpr int NSP = 2;                   // halves of an input fragment
     constexpr int NFR = BW * NCI * NSP;      // input fragments per board row
     constexpr int NB = NCI * 3;              // (32-channel block, tap row) slabs per input row
-    constexpr int NPR = FIRST ? 2 : 3;       // MFMA products per multiply-add
+    constexpr int NPR = 3;                   // MFMA products per multiply-add
     const int kq = lane >> 4, b = lane & 15;
     const int lane16 = lane * 16;
     // per-lane byte offset of this lane's 4 output channels inside a (cell, 32-channel block) fragment pair
@@ -623,15 +624,17 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
         }
     }
     // conv1: one fragment = channels 8*kq .. 8*kq+7 of (cell, board b) = two float4 quads of the fp32 batch
-    auto load_planes = [&](int cell) -> half8 {
+    auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
         const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
         const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
         const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
         half8 h;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            h[k] = static_cast<_Float16>(__uint_as_float(q0[k]));
-            h[4 + k] = static_cast<_Float16>(__uint_as_float(q1[k]));
+            const float v0 = __uint_as_float(q0[k]), v1 = __uint_as_float(q1[k]);
+            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
+            h[k] = split ? static_cast<_Float16>(v0 - static_cast<float>(h0)) : h0;
+            h[4 + k] = split ? static_cast<_Float16>(v1 - static_cast<float>(h1)) : h1;
         }
         return h;
     };
@@ -686,7 +689,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     // stage input row 0 (wave w copies fragments w, w + NT, ...)
     __syncthreads();  // the previous layer is done with both row buffers
     for (int f = tile; f < NFR; f += NT) {
-        if (FIRST) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f));
+        if (FIRST) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f >> 1, f & 1));
         else s_x[f * 64 + lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, f * 1024, 0));
     }
     load_w(0, wA);
@@ -709,7 +712,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
                 for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
                     const int f = tile + NT * (c * ((NFR / NT + NCI) / NCI) + k);
                     if (f < NFR) {
-                        if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + f));
+                        if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
                         else
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
                                                                      16, lane16, (yn * NFR + f) * 1024, 0, 0);
@@ -719,13 +722,13 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             const int yo = yi + 1 - dy;
             if (yo >= 0 && yo < BW) {   // (uniform)
                 half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
-                half8 xl = FIRST ? xh : __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                half8 xl = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 1) * 64 + lane]);
 #pragma unroll
                 for (int xi = 0; xi < BW; ++xi) {
                     half8 nh = xh, nl = xl;
                     if (xi + 1 < BW) {
                         nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 0) * 64 + lane]);
-                        if (!FIRST) nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                        nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 1) * 64 + lane]);
                     }
                     // input cell (yi, xi) feeds output row yo at cells xi-dx+1: xh*wh, xh*wl, xl*wh, ordered so that
                     // consecutive MFMAs hit different accumulators
@@ -777,10 +780,10 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
     constexpr bool HALO = XT < BW;
     constexpr int NX = HALO ? XT + 2 : XT;   // staged input cells per row; staged cell j = board column x0 - 1 + j (HALO) or j
     constexpr int NT = NC32 * 2;
-    constexpr int NSP = FIRST ? 1 : 2;
+    constexpr int NSP = 2;
     constexpr int NFR = NX * NCI * NSP;
     constexpr int NB = NCI * 3;
-    constexpr int NPR = FIRST ? 2 : 3;
+    constexpr int NPR = 3;
     const int kq = lane >> 4, b = lane & 15;
     const int lane16 = lane * 16;
     const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
@@ -808,15 +811,17 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
         }
     }
-    auto load_planes = [&](int cell) -> half8 {
+    auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
         const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
         const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
         const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
         half8 h;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            h[k] = static_cast<_Float16>(__uint_as_float(q0[k]));
-            h[4 + k] = static_cast<_Float16>(__uint_as_float(q1[k]));
+            const float v0 = __uint_as_float(q0[k]), v1 = __uint_as_float(q1[k]);
+            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
+            h[k] = split ? static_cast<_Float16>(v0 - static_cast<float>(h0)) : h0;
+            h[4 + k] = split ? static_cast<_Float16>(v1 - static_cast<float>(h1)) : h1;
         }
         return h;
     };
@@ -831,7 +836,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
                 if (xin < 0 || xin >= BW) {
                     xb[f * 64 + lane] = make_uint4(0, 0, 0, 0);   // halo column outside the board
                 } else if (FIRST) {
-                    xb[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(y * BW + xin));
+                    xb[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(y * BW + xin, rest));
                 } else {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + f * 64), 16,
                                                              lane16, ((y * BW + xin) * NCI * 2 + rest) * 1024, 0, 0);
@@ -897,13 +902,13 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             const int yo = yi + 1 - dy;
             if (yo >= yb && yo < ye) {   // (uniform)
                 half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
-                half8 xl = FIRST ? xh : __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                half8 xl = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 1) * 64 + lane]);
 #pragma unroll
                 for (int j = 0; j < NX; ++j) {
                     half8 nh = xh, nl = xl;
                     if (j + 1 < NX) {
                         nh = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + 0) * 64 + lane]);
-                        if (!FIRST) nl = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + NSP - 1) * 64 + lane]);
+                        nl = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + 1) * 64 + lane]);
                     }
 #pragma unroll
                     for (int pr = 0; pr < NPR; ++pr) {

@@ -174,3 +174,24 @@ def test_full_size_batch_all_paths_agree():
         assert np.abs(outs[m][0][idx] - rp.numpy()).max() < TOL, m
         assert np.abs(outs[m][1][idx] - rv.numpy()).max() < TOL, m
     net.close()
+
+
+@pytest.mark.parametrize("B,batch", [(9, 4096), (9, 40), (15, 24)])
+def test_split_fp16_forward_takes_arbitrary_float_planes(B, batch):
+    """ao_net_forward's input is any float32 planes, not only the engine's 0/1 planes: conv1 of the split-fp16
+    kernels (resident for 4096 boards, per layer otherwise) splits its input like every other layer."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    torch.manual_seed(B + batch)
+    ref = PVNet(2, 5, 128, B).eval()
+    x = torch.randn(batch, 5, B, B) * 3.0
+    net = ref.to_native(0)
+    net.set_mode(5)
+    p, v = net(x.cuda())
+    torch.cuda.synchronize()
+    idx = np.arange(batch) if batch <= 64 else np.random.RandomState(0).choice(batch, 64, replace=False)
+    with torch.no_grad():
+        rp, rv = ref(x[idx])
+    assert np.abs(p.cpu().numpy()[idx] - rp.numpy()).max() < TOL
+    assert np.abs(v.cpu().numpy()[idx] - rv.numpy()).max() < TOL
+    net.close()
