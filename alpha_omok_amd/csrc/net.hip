@@ -447,6 +447,94 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    if (H16) {
+        // Both FC layers for the 16 boards AT ONCE: a weight is loaded once and used for all 16 boards (one
+        // wave per board re-read the 93 KB of FC weights 16 times: ~60 us per group). Waves split the input
+        // index j, lanes the outputs, every lane keeps 16 board accumulators per output; partial sums meet in LDS.
+        float* s_pp = s_h + GB * 3 * A;        // [nw][GB][A]      policy_fc partials
+        float* s_vp = s_pp + nw * GB * A;      // [nw][GB][planes] value_fc1 partials
+        const int NP = (planes + 63) / 64;
+        {
+            const int js = (2 * A + nw - 1) / nw, j0 = wave * js, j1 = min(2 * A, j0 + js);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const int o = lane + 64 * c;
+                float acc[GB];
+#pragma unroll
+                for (int bb = 0; bb < GB; ++bb) acc[bb] = 0.f;
+                if (o < A) {
+                    for (int j = j0; j < j1; ++j) {
+                        const float w = a.wp_t[static_cast<size_t>(j) * A + o];
+#pragma unroll
+                        for (int bb = 0; bb < GB; ++bb) acc[bb] = fmaf(w, s_h[bb * 3 * A + j], acc[bb]);
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < GB; ++bb) s_pp[(wave * GB + bb) * A + o] = acc[bb];
+                }
+            }
+        }
+        {
+            const int js = (A + nw - 1) / nw, j0 = wave * js, j1 = min(A, j0 + js);
+            for (int c = 0; c < NP; ++c) {
+                const int o = lane + 64 * c;
+                float acc[GB];
+#pragma unroll
+                for (int bb = 0; bb < GB; ++bb) acc[bb] = 0.f;
+                if (o < planes) {
+                    for (int j = j0; j < j1; ++j) {
+                        const float w = a.w1_t[static_cast<size_t>(j) * planes + o];
+#pragma unroll
+                        for (int bb = 0; bb < GB; ++bb) acc[bb] = fmaf(w, s_h[bb * 3 * A + 2 * A + j], acc[bb]);
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < GB; ++bb) s_vp[(wave * GB + bb) * planes + o] = acc[bb];
+                }
+            }
+        }
+        __syncthreads();
+        for (int bb = wave; bb < GB; bb += nw) {   // softmax / tanh: one wave per board
+            const size_t board = static_cast<size_t>(grp) * GB + bb;
+            float lg[NA];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const int o = lane + 64 * c;
+                lg[c] = -3.0e38f;
+                if (o < A) {
+                    float t = a.bp[o];
+                    for (int q = 0; q < nw; ++q) t += s_pp[(q * GB + bb) * A + o];
+                    lg[c] = t;
+                    mx = fmaxf(mx, t);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const int o = lane + 64 * c;
+                lg[c] = (o < A) ? expf(lg[c] - mx) : 0.f;
+                sum += lg[c];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const int o = lane + 64 * c;
+                if (o < A) a.policy[board * A + o] = lg[c] / sum;
+            }
+            float part = 0.f;
+            for (int o = lane; o < planes; o += 64) {
+                float t = a.b1[o];
+                for (int q = 0; q < nw; ++q) t += s_vp[(q * GB + bb) * planes + o];
+                part = fmaf(a.w2[o], fmaxf(t, 0.f), part);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            if (lane == 0) a.value[board] = tanhf(part + a.b2[0]);
+        }
+        return;
+    }
     for (int bb = wave; bb < GB; bb += nw) {
         const float* h = s_h + bb * 3 * A;
         const size_t board = static_cast<size_t>(grp) * GB + bb;
@@ -1520,7 +1608,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
-        constexpr size_t lds_ = static_cast<size_t>(2) * W * 4 * 2 * 1024;                                   \
+        constexpr size_t heads_ = (static_cast<size_t>(3) * 128 + 16 * 3 * W * W + 8 * 16 * W * W + 8 * 16 * 128) * 4;  \
+        constexpr size_t lds_ = (static_cast<size_t>(2) * W * 4 * 2 * 1024 > heads_) ? static_cast<size_t>(2) * W * 4 * 2 * 1024 : heads_; \
         if (!attr_done[W]) {                                                                                 \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
