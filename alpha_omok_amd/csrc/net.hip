@@ -599,11 +599,14 @@ __global__ __launch_bounds__(256 * (3 - TPW), 1) void k_trunk16(TrunkArgs a) {
         // even l > 0: second conv of a ResBlock, + x (held in bufA = dst)
         trunk_layer<BW, XT, TPW>(src, dst, a.layers[l].w, a.layers[l].sc, a.layers[l].sh, l > 0 && (l & 1) == 0,
                                  l == 0 ? a.cq0 : a.CQ, l == 0 ? a.cq0_real : a.CQ, a.COUT, gbase, ct0, kq, b, 0, BW);
-        // layer boundary inside the workgroup: all stores of this layer acknowledged by L2, then
-        // drop this CU's L1 so the next layer reads what the other waves wrote (same XCD L2).
+        // layer boundary inside the workgroup: all stores of this layer acknowledged, then a WORKGROUP-scope
+        // acquire. The group's activations are private to this workgroup, whose waves share one CU and one L1
+        // (write-through, coherent for the CU's own stores), so nothing has to be invalidated; the agent-scope
+        // acquire used at first (buffer_inv sc1) made every CU re-fetch its working set after each layer -- 15 k
+        // cycles per layer of the split-fp16 kernel (AO_PROF phase timing).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     // the trunk output of this group (bufA: nlayers is odd) is still in this XCD's L2: run both heads
     trunk_heads<BW>(a, a.bufA, gbase, grp);
@@ -667,13 +670,25 @@ __device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
 
+#ifdef AO_PROF
+// phase timing of k_trunk16h (build with AO_EXTRA_FLAGS=-DAO_PROF; tools/time_net.py prints it): shader-clock
+// cycles per wave of one group, summed over the trunk layers: [0] row-0 staging, [1] slab loops, [2] row
+// epilogues, [3] row barriers, [4] last epilogue + layer boundary, [5] heads, [6] conv1 total
+__device__ unsigned long long ao_prof[8 * 12];
+#define AO_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define AO_ACC(k, t0, t1) prof[k] += (t1) - (t0)
+#else
+#define AO_T(x)
+#define AO_ACC(k, t0, t1)
+#endif
+
 // One conv layer of one 16-board group. NCI = 32-channel blocks of the INPUT (NC32 for a trunk layer).
 // FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real); it
 // is split into its two halves while it is staged (the engine's planes are 0/1 and have a zero low half, but
 // ao_net_forward accepts any float planes).
 template <int BW, int NC32, int NCI, bool FIRST>
 __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
-                                              int tile, int lane) {
+                                              int tile, int lane, unsigned long long* prof) {
     constexpr int A = BW * BW;
     constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
     constexpr int NSP = 2;                   // halves of an input fragment
@@ -775,15 +790,40 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     };
 
     // stage input row 0 (wave w copies fragments w, w + NT, ...)
+    AO_T(t_a);
     __syncthreads();  // the previous layer is done with both row buffers
-    for (int f = tile; f < NFR; f += NT) {
-        if (FIRST) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f >> 1, f & 1));
-        else s_x[f * 64 + lane] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, lane16, f * 1024, 0));
+    AO_T(t_a1);
+    // (all loads of the wave in flight at once: written as a loop over f the compiler emits load, wait, LDS write
+    // per fragment -- nine serial HBM round trips, 10 us per layer)
+    if (FIRST) {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;
+            if (f < NFR) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f >> 1, f & 1));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;
+            if (f < NFR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
+                                                         f * 1024, 0, 0);
+        }
     }
+    AO_T(t_a2);
     load_w(0, wA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    AO_T(t_a3);
     __syncthreads();
+    AO_T(t_b);
+    AO_ACC(0, t_a, t_b);
+    AO_ACC(8, t_a, t_a1);
+    AO_ACC(9, t_a1, t_a2);
+    AO_ACC(10, t_a2, t_a3);
+    AO_ACC(11, t_a3, t_b);
 
     for (int yi = 0; yi < BW; ++yi) {
+        AO_T(t_r0);
         const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
         uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
         const int yn = yi + 1 < BW ? yi + 1 : yi;                               // next input row (clamped)
@@ -838,6 +878,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        AO_T(t_r1);
         if (yi >= 1) epilogue(yi - 1);
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
@@ -845,14 +886,22 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             acc[1][i] = acc[2][i];
             acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        AO_T(t_r2);
         // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        AO_T(t_r3);
+        AO_ACC(1, t_r0, t_r1);
+        AO_ACC(2, t_r1, t_r2);
+        AO_ACC(3, t_r2, t_r3);
     }
+    AO_T(t_c);
     epilogue(BW - 1);
     // layer boundary inside the workgroup (see k_trunk16)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    AO_T(t_d);
+    AO_ACC(4, t_c, t_d);
 }
 
 // The same layer for ONE (row chunk [yb, ye), column tile x0 .. x0+XT-1) of a group: the per-layer form for
@@ -1067,14 +1116,30 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first activation fragment of this group
     uint4* bufA = a.bufA + gfrag * 64;
     uint4* bufB = a.bufB + gfrag * 64;
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* pp = prof;
     // conv1: fp32 planes -> x
-    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane);
+    AO_T(t0);
+    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp);
+    AO_T(t1);
+#ifdef AO_PROF
+    for (int k = 0; k < 12; ++k) prof[k] = 0;
+#endif
     for (int l = 1; l < a.nlayers; ++l) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
-        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane);
+        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp);
     }
+    AO_T(t2);
     trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
+#ifdef AO_PROF
+    AO_T(t3);
+    prof[5] = t3 - t2;
+    prof[6] = t1 - t0;
+    prof[7] = t3 - t0;
+    if (grp == 5 && lane == 0)
+        for (int k = 0; k < 12; ++k) ao_prof[tile * 12 + k] = prof[k];
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1529,7 +1594,11 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                            reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
         return 0;
+#ifdef AO_PROF
+    } else if (group == 16 && mode == 5 && !(n->B <= 9 && (groups >= 192 || getenv("AO_FORCE_RESIDENT")))) {
+#else
     } else if (group == 16 && mode == 5 && !(n->B <= 9 && groups >= 192)) {
+#endif
         // split-fp16 trunk, one launch per conv: workgroup = (16-board group, row chunk, column tile). For batches
         // that cannot give every CU a whole group, and for boards wider than 9 (a staged row must fit LDS twice)
         const int nxt = n->B <= 9 ? 1 : (n->B + 4) / 5;
@@ -1623,6 +1692,20 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         }
         if (n->timing) timer_end(n, idx, s);
         NET_HIP(n, hipGetLastError());
+#ifdef AO_PROF
+        if (getenv("AO_PROF_PRINT")) {
+            unsigned long long h[96];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof), sizeof(h));
+            static const char* nm[12] = {"stage0", "slabs", "epilogue", "barrier", "last_epi+boundary", "heads", "conv1", "total",
+                                         "s0:sync1", "s0:stage-issue", "s0:loads-land", "s0:sync2"};
+            for (int k = 0; k < 12; ++k) {
+                fprintf(stderr, "AO_PROF %-18s", nm[k]);
+                for (int t = 0; t < 8; ++t) fprintf(stderr, " %9llu", h[t * 12 + k]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         return 0;  // the heads ran inside the resident kernel
     } else if (group == 16 && mode == 4) {
         auto layer = [&](int l, const float* in, int cqi, int cq_real, bool res, float* out) {
