@@ -134,8 +134,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # AO_BENCH_BACKEND=gloo + AO_BENCH_SHARE_GPU=1 exercise this path with two ranks on a 1-GPU box
+        backend = os.environ.get("AO_BENCH_BACKEND", "nccl")
+        if os.environ.get("AO_BENCH_SHARE_GPU"):
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -196,7 +203,7 @@ def main():
     dt = time.perf_counter() - t0
     conv_ms, conv_launches = net.conv_timing(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
