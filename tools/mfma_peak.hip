@@ -62,6 +62,68 @@ __global__ void kh(float* out, int iters, unsigned seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// v_mfma_f32_32x32x16_f16 (32768 FLOP, half the operand bytes per FLOP of the 16x16x32 form), same operand recipe
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NACC, bool NOISY>
+__global__ void kh32(float* out, int iters, unsigned seed) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    half8 a[3], b[4];
+    unsigned h = seed + threadIdx.x * 2654435761u;
+    auto mk = [&]() {
+        u32x4 q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h = h * 1664525u + 1013904223u;
+            q[k] = NOISY ? ((h & 0x83ff83ffu) | 0x38003800u | ((h >> 3) & 0x04000400u)) : 0x3c003c00u;
+        }
+        return __builtin_bit_cast(half8, q);
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = mk();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = mk();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + r) % 3], b[(i * 4 + r) % 4], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += acc[i][k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NACC, bool NOISY>
+void run_h32(int waves_per_cu, const char* tag, int iters = 20000) {
+    float* d;
+    hipMalloc(&d, 256 * 1024 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((kh32<NACC, NOISY>), dim3(256), dim3(64 * waves_per_cu), 0, 0, d, 100, 1u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kh32<NACC, NOISY>), dim3(256), dim3(64 * waves_per_cu), 0, 0, d, iters, 1u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double mfma = 256.0 * waves_per_cu * iters * 4.0 * NACC;
+    const double tf = mfma * 32768.0 / (ms * 1e-3) / 1e12;
+    const double cyc = (ms * 1e-3 * 2.4e9) / (mfma / 1024.0);
+    printf("f16 32x32x16 %s %s: %d waves/CU, %d acc: %.3f ms, %.1f TFLOP/s, %.2f cycles/MFMA/SIMD at 2.4 GHz\n", tag,
+           NOISY ? "random operands" : "constant operands", waves_per_cu, NACC, ms, tf, cyc);
+    hipFree(d);
+}
+
 template <int NACC, bool NOISY>
 void run_h(int waves_per_cu, const char* tag, int iters = 40000) {
     float* d;
@@ -123,5 +185,10 @@ int main() {
     run_h<9, true>(8, "2 waves/SIMD (again, warm)");
     run_h<9, true>(8, "2 waves/SIMD, 0.5 s sustained", 800000);
     run_h<9, true>(8, "2 waves/SIMD, after that", 40000);
+    run_h32<4, false>(8, "2 waves/SIMD");
+    run_h32<4, true>(8, "2 waves/SIMD");
+    run_h32<4, true>(8, "2 waves/SIMD (again, warm)");
+    run_h32<4, true>(8, "2 waves/SIMD, 0.5 s sustained", 400000);
+    run_h<9, true>(8, "16x16x32 again");
     return 0;
 }
