@@ -41,6 +41,7 @@ sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: ~2.5 PFLOP/s dense fp16 / bf16 MFMA
+SUSTAINED_F16_MFMA_TFLOPS = 2050.0  # measured: pure v_mfma_f32_16x16x32_f16 stream, data-like operands (power limit)
 
 
 def trunk_conv_flops(board, planes, boards):
@@ -266,6 +267,16 @@ def main():
                 "frac": achieved / peak,
                 "mfma_dtype": "f16" if split16 else "f32",
                 "executed_tflops": achieved * 3.0 if split16 else achieved,
+                # orientation beside `frac` (which prices the ALGORITHMIC fp32 FLOPs against the nominal fp16 peak):
+                # the MFMAs really issued (taps that fall off the board are skipped: (3B-2)^2 of (3B)^2) against the
+                # rate the pipe sustains on data-like operands under the chip's power limit, measured with
+                # tools/mfma_peak.hip (profiles/r1j_mfma_peak_microbench.txt), and the fp32-MFMA peak the same
+                # algorithmic work would be priced against if it ran on v_mfma_f32_16x16x4_f32
+                "issued_tflops": achieved * (3.0 if split16 else 1.0) * ((3 * B - 2) ** 2) / float((3 * B) ** 2),
+                "sustained_peak_measured": SUSTAINED_F16_MFMA_TFLOPS if split16 else 156.0,
+                "issued_frac_of_sustained": achieved * (3.0 if split16 else 1.0) * ((3 * B - 2) ** 2) / float((3 * B) ** 2)
+                                            / (SUSTAINED_F16_MFMA_TFLOPS if split16 else 156.0),
+                "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)"
                                 % (os.path.relpath(traffic_src, REPO) if traffic_src else "no profile"),
