@@ -686,6 +686,16 @@ __device__ unsigned long long ao_prof[8 * 12];
 // FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real); it
 // is split into its two halves while it is staged (the engine's planes are 0/1 and have a zero low half, but
 // ao_net_forward accepts any float planes).
+// Knock-out switches for timing experiments (-DAO_KO=n together with -DAO_PROF; RESULTS ARE WRONG for n != 0, the
+// default build has AO_KO = 0 and every condition below folds away): 1 weights loaded for the first slabs only,
+// 2 LDS operand fragments read once per slab, 3 no staging of input rows, 4 no row epilogues (residual loads +
+// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint. Measured: profiles/r1j_trunk16h_phase_timing.txt
+#ifndef AO_KO
+#define AO_KO 0
+#endif
+#if AO_KO != 0 && !defined(AO_PROF)
+#error "AO_KO builds compute wrong results on purpose: timing only, build them with -DAO_PROF"
+#endif
 template <int BW, int NC32, int NCI, bool FIRST>
 __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
                                               int tile, int lane, unsigned long long* prof) {
@@ -711,6 +721,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
     auto load_w = [&](int slab, half8 (&W)[2][3]) {
         if (FIRST) return;
+        if (AO_KO == 1 && slab > 2) return;
         const int c = (slab / 3) % NCI, dy = slab % 3;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -834,7 +845,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             half8 (&w)[2][3] = (slab & 1) ? wB : wA;
             half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
             load_w(slab + 1, wn);
-            if (dy == 1) {
+            if (dy == 1 && AO_KO != 3) {
                 // next input row into LDS, a share per block (always-executed slab)
 #pragma unroll
                 for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
@@ -854,7 +865,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
 #pragma unroll
                 for (int xi = 0; xi < BW; ++xi) {
                     half8 nh = xh, nl = xl;
-                    if (xi + 1 < BW) {
+                    if (xi + 1 < BW && AO_KO != 2) {
                         nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 0) * 64 + lane]);
                         nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 1) * 64 + lane]);
                     }
@@ -879,7 +890,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             __builtin_amdgcn_sched_barrier(0);
         }
         AO_T(t_r1);
-        if (yi >= 1) epilogue(yi - 1);
+        if (yi >= 1 && (AO_KO != 4 || yi == 1)) epilogue(yi - 1);
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
             acc[0][i] = acc[1][i];
@@ -1113,7 +1124,8 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
-    const size_t gfrag = static_cast<size_t>(grp) * A * NC32 * 2;  // first activation fragment of this group
+    // first activation fragment of this group (AO_KO 5 / 6: groups share buffers, timing experiment only)
+    const size_t gfrag = static_cast<size_t>(AO_KO == 5 ? grp % 64 : AO_KO == 6 ? grp % 128 : grp) * A * NC32 * 2;
     uint4* bufA = a.bufA + gfrag * 64;
     uint4* bufB = a.bufB + gfrag * 64;
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
