@@ -1,0 +1,527 @@
+// net_trunk_h16.hpp -- the conv stack with the fp32 contraction carried by fp16 MFMAs on split operands:
+// k_trunk16h (group-resident) and k_layer16h (per layer). Included by net.hip after net_trunk_f32.hpp
+// (trunk_heads is shared).
+#pragma once
+
+namespace ao {
+
+// ----------------------------------------------------------------------------------------------
+struct TrunkHLayer {
+    const uint4* wh;   // [tap 9][c32][tile][lane 64] 8 x fp16: high halves, lane = oct*16 + cout
+    const uint4* wl;   // low halves
+    const float4* sc;  // BatchNorm scale x 2^-s (s = the layer's weight pre-scale)
+    const float4* sh;
+};
+
+struct TrunkHArgs {
+    const float4* in0;  // fp32 plane batch [grp][cell][quad 8][board 16] (conv1 input)
+    uint4* bufA;  // conv1 output / ResBlock input-output (split-fp16 layout)
+    uint4* bufB;
+    int nlayers;  // 1 + 2 * n_block, conv1 included
+    int CQ, COUT;
+    const float *w3, *sc3, *sh3, *wp_t, *bp, *w1_t, *b1, *w2, *b2;
+    float* policy;
+    float* value;
+    TrunkHLayer layers[kMaxTrunkLayers];
+};
+
+// All global traffic of k_trunk16h goes through buffer descriptors: address = descriptor base + one
+// 32-bit per-lane offset (VGPR) + a uniform offset (SGPR). With plain pointers the compiler keeps a 64-bit
+// address VGPR pair per access site, hoists them out of the loops and spills them (270 registers in
+// the first version of this kernel).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half8 buf_ld_h8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ half4 buf_ld_h4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+
+#ifdef AO_PROF
+// phase timing of k_trunk16h (build with AO_EXTRA_FLAGS=-DAO_PROF; tools/time_net.py prints it): shader-clock
+// cycles per wave of one group, summed over the trunk layers: [0] row-0 staging, [1] slab loops, [2] row
+// epilogues, [3] row barriers, [4] last epilogue + layer boundary, [5] heads, [6] conv1 total
+__device__ unsigned long long ao_prof[8 * 12];
+#define AO_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define AO_ACC(k, t0, t1) prof[k] += (t1) - (t0)
+#else
+#define AO_T(x)
+#define AO_ACC(k, t0, t1)
+#endif
+
+// One conv layer of one 16-board group. NCI = 32-channel blocks of the INPUT (NC32 for a trunk layer).
+// FIRST = conv1: the input is the fp32 plane batch ([cell][quad 8][board 16][float4], 32 channels, 5 real); it
+// is split into its two halves while it is staged (the engine's planes are 0/1 and have a zero low half, but
+// ao_net_forward accepts any float planes).
+// Knock-out switches for timing experiments (-DAO_KO=n together with -DAO_PROF; RESULTS ARE WRONG for n != 0, the
+// default build has AO_KO = 0 and every condition below folds away): 1 weights loaded for the first slabs only,
+// 2 LDS operand fragments read once per slab, 3 no staging of input rows, 4 no row epilogues (residual loads +
+// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint. Measured: profiles/r1j_trunk16h_phase_timing.txt
+#ifndef AO_KO
+#define AO_KO 0
+#endif
+#if AO_KO != 0 && !defined(AO_PROF)
+#error "AO_KO builds compute wrong results on purpose: timing only, build them with -DAO_PROF"
+#endif
+template <int BW, int NC32, int NCI, bool FIRST>
+__device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
+                                              int tile, int lane, unsigned long long* prof) {
+    constexpr int A = BW * BW;
+    constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
+    constexpr int NSP = 2;                   // halves of an input fragment
+    constexpr int NFR = BW * NCI * NSP;      // input fragments per board row
+    constexpr int NB = NCI * 3;              // (32-channel block, tap row) slabs per input row
+    constexpr int NPR = 3;                   // MFMA products per multiply-add
+    const int kq = lane >> 4, b = lane & 15;
+    const int lane16 = lane * 16;
+    // per-lane byte offset of this lane's 4 output channels inside a (cell, 32-channel block) fragment pair
+    const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+    // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of the
+    // SIMD computes meanwhile)
+    // (conv1 has a single 32-channel block: its 9 x 2 fragments are simply loaded once)
+    half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
+    auto load_w = [&](int slab, half8 (&W)[2][3]) {
+        if (FIRST) return;
+        if (AO_KO == 1 && slab > 2) return;
+        const int c = (slab / 3) % NCI, dy = slab % 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+            W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+        }
+    };
+    if (FIRST) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
+            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+        }
+    }
+    // conv1: one fragment = channels 8*kq .. 8*kq+7 of (cell, board b) = two float4 quads of the fp32 batch
+    auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
+        const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
+        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
+        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
+        half8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = __uint_as_float(q0[k]), v1 = __uint_as_float(q1[k]);
+            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
+            h[k] = split ? static_cast<_Float16>(v0 - static_cast<float>(h0)) : h0;
+            h[4 + k] = split ? static_cast<_Float16>(v1 - static_cast<float>(h1)) : h1;
+        }
+        return h;
+    };
+    f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Output row in two batches of cells: all residual loads of a batch are issued before the first is used
+    // (written cell by cell the compiler produced load, wait, store, load, wait-for-everything ...: nine serial
+    // memory round trips per row, 3.8 us; the registers of the X fragments are free here)
+    auto epilogue = [&](int yo) {
+        constexpr int HB = (BW + 1) / 2;
+#pragma unroll
+        for (int i0 = 0; i0 < BW; i0 += HB) {
+            half4 rh[HB], rl[HB];
+            if (RES) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const int i = i0 + k < BW ? i0 + k : BW - 1;
+                    const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                    rh[k] = buf_ld_h4(rs_dst, out_voff, ob);
+                    rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int i = i0 + k;
+                if (i >= BW) continue;
+                const f32x4 c = acc[0][i];
+                float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+                const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
+                }
+                half4 hh, hl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
+                    // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN
+                    const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
+                    hh[r] = static_cast<_Float16>(v);
+                    hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+                }
+                buf_st_h4(hh, rs_dst, out_voff, ob);
+                buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+            }
+        }
+    };
+
+    // stage input row 0 (wave w copies fragments w, w + NT, ...)
+    AO_T(t_a);
+    __syncthreads();  // the previous layer is done with both row buffers
+    AO_T(t_a1);
+    // (all loads of the wave in flight at once: written as a loop over f the compiler emits load, wait, LDS write
+    // per fragment -- nine serial HBM round trips, 10 us per layer)
+    if (FIRST) {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;
+            if (f < NFR) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f >> 1, f & 1));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;
+            if (f < NFR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
+                                                         f * 1024, 0, 0);
+        }
+    }
+    AO_T(t_a2);
+    load_w(0, wA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    AO_T(t_a3);
+    __syncthreads();
+    AO_T(t_b);
+    AO_ACC(0, t_a, t_b);
+    AO_ACC(8, t_a, t_a1);
+    AO_ACC(9, t_a1, t_a2);
+    AO_ACC(10, t_a2, t_a3);
+    AO_ACC(11, t_a3, t_b);
+
+    for (int yi = 0; yi < BW; ++yi) {
+        AO_T(t_r0);
+        const uint4* xs = s_x + static_cast<size_t>(yi & 1) * NFR * 64;         // this row
+        uint4* xn = s_x + static_cast<size_t>((yi + 1) & 1) * NFR * 64;         // next row's buffer
+        const int yn = yi + 1 < BW ? yi + 1 : yi;                               // next input row (clamped)
+#pragma unroll
+        for (int slab = 0; slab < NB; ++slab) {
+            const int c = slab / 3, dy = slab % 3;
+            // (NB is even for the trunk layers: the buffer parity carries over from one row to the next)
+            half8 (&w)[2][3] = (slab & 1) ? wB : wA;
+            half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
+            load_w(slab + 1, wn);
+            if (dy == 1 && AO_KO != 3) {
+                // next input row into LDS, a share per block (always-executed slab)
+#pragma unroll
+                for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
+                    const int f = tile + NT * (c * ((NFR / NT + NCI) / NCI) + k);
+                    if (f < NFR) {
+                        if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
+                        else
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
+                                                                     16, lane16, (yn * NFR + f) * 1024, 0, 0);
+                    }
+                }
+            }
+            const int yo = yi + 1 - dy;
+            if (yo >= 0 && yo < BW) {   // (uniform)
+                half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
+                half8 xl = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 1) * 64 + lane]);
+#pragma unroll
+                for (int xi = 0; xi < BW; ++xi) {
+                    half8 nh = xh, nl = xl;
+                    if (xi + 1 < BW && AO_KO != 2) {
+                        nh = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 0) * 64 + lane]);
+                        nl = __builtin_bit_cast(half8, xs[(((xi + 1) * NCI + c) * NSP + 1) * 64 + lane]);
+                    }
+                    // input cell (yi, xi) feeds output row yo at cells xi-dx+1: xh*wh, xh*wl, xl*wh, ordered so that
+                    // consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int i = xi - dx + 1;
+                            if (i < 0 || i >= BW) continue;
+                            const half8 wv = FIRST ? wres[pr == 1 ? 1 : 0][FIRST ? dy * 3 + dx : 0] : w[pr == 1 ? 1 : 0][dx];
+                            acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, pr == 2 ? xl : xh, acc[2 - dy][i], 0, 0, 0);
+                        }
+                    }
+                    xh = nh;
+                    xl = nl;
+                    // keeps the scheduler from hoisting every LDS read of the slab to its top (72 registers)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        AO_T(t_r1);
+        if (yi >= 1 && (AO_KO != 4 || yi == 1)) epilogue(yi - 1);
+#pragma unroll
+        for (int i = 0; i < BW; ++i) {
+            acc[0][i] = acc[1][i];
+            acc[1][i] = acc[2][i];
+            acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        AO_T(t_r2);
+        // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        AO_T(t_r3);
+        AO_ACC(1, t_r0, t_r1);
+        AO_ACC(2, t_r1, t_r2);
+        AO_ACC(3, t_r2, t_r3);
+    }
+    AO_T(t_c);
+    epilogue(BW - 1);
+    // layer boundary inside the workgroup (see k_trunk16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    AO_T(t_d);
+    AO_ACC(4, t_c, t_d);
+}
+
+// The same layer for ONE (row chunk [yb, ye), column tile x0 .. x0+XT-1) of a group: the per-layer form for
+// batches too small to give every CU a whole group (k_layer16h: one launch per conv, workgroup = group x row
+// chunk x column tile) and for boards whose rows do not fit LDS (15 x 15: XT = 5, a staged row is the tile
+// plus one halo column on each side = 7 cells = 56 KB, two of them 112 KB). Halo columns that fall off the
+// board are staged as zeros, so the MFMA stream needs no per-column conditions; halo rows are handled by the
+// slab conditions (uniform per row) exactly as in the fp32 row-chunk kernel.
+template <int BW, int XT, int NC32, int NCI, bool FIRST>
+__device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES,
+                                                   uint4* s_x, int tile, int lane, int x0, int yb, int ye) {
+    constexpr int A = BW * BW;
+    constexpr bool HALO = XT < BW;
+    constexpr int NX = HALO ? XT + 2 : XT;   // staged input cells per row; staged cell j = board column x0 - 1 + j (HALO) or j
+    constexpr int NT = NC32 * 2;
+    constexpr int NSP = 2;
+    constexpr int NFR = NX * NCI * NSP;
+    constexpr int NB = NCI * 3;
+    constexpr int NPR = 3;
+    const int kq = lane >> 4, b = lane & 15;
+    const int lane16 = lane * 16;
+    const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+    half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
+    auto load_w = [&](int slab, half8 (&W)[2][3]) {
+        if (FIRST) return;
+        const int c = (slab / 3) % NCI, dy = slab % 3;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+            W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+        }
+    };
+    if (FIRST) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
+            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+        }
+    }
+    auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
+        const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
+        const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
+        const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
+        half8 h;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = __uint_as_float(q0[k]), v1 = __uint_as_float(q1[k]);
+            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
+            h[k] = split ? static_cast<_Float16>(v0 - static_cast<float>(h0)) : h0;
+            h[4 + k] = split ? static_cast<_Float16>(v1 - static_cast<float>(h1)) : h1;
+        }
+        return h;
+    };
+    // stage this wave's share of input row y into row buffer `xb`
+    auto stage = [&](int y, uint4* xb) {
+#pragma unroll
+        for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
+            const int f = tile + NT * k;   // staged fragment: (cell j, block c, half)
+            if (f < NFR) {
+                const int j = f / (NCI * NSP), rest = f - j * (NCI * NSP);
+                const int xin = HALO ? x0 - 1 + j : j;
+                if (xin < 0 || xin >= BW) {
+                    xb[f * 64 + lane] = make_uint4(0, 0, 0, 0);   // halo column outside the board
+                } else if (FIRST) {
+                    xb[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(y * BW + xin, rest));
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + f * 64), 16,
+                                                             lane16, ((y * BW + xin) * NCI * 2 + rest) * 1024, 0, 0);
+                }
+            }
+        }
+    };
+    f32x4 acc[3][XT];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < XT; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto epilogue = [&](int yo) {
+        // all residual loads of the row first (see trunk_h_layer)
+        half4 rh[XT], rl[XT];
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) {
+                const int xo = x0 + i < BW ? x0 + i : BW - 1;
+                const int ob = (((yo * BW + xo) * NC32 + (tile >> 1)) * 2) * 1024;
+                rh[i] = buf_ld_h4(rs_dst, out_voff, ob);
+                rl[i] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            if (x0 + i >= BW) continue;   // (only when XT does not divide BW; uniform)
+            const f32x4 c = acc[0][i];
+            float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+            const int ob = (((yo * BW + x0 + i) * NC32 + (tile >> 1)) * 2) * 1024;
+            if (RES) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[i][r]) + static_cast<float>(rl[i][r]);
+            }
+            half4 hh, hl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
+                hh[r] = static_cast<_Float16>(v);
+                hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+            }
+            buf_st_h4(hh, rs_dst, out_voff, ob);
+            buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+        }
+    };
+
+    const int y0 = yb > 0 ? yb - 1 : 0;          // input rows that feed output rows [yb, ye)
+    const int y1 = ye < BW ? ye : BW - 1;
+    stage(y0, s_x);
+    load_w(0, wA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int yi = y0; yi <= y1; ++yi) {
+        const int par = (yi - y0) & 1;
+        const uint4* xs = s_x + static_cast<size_t>(par) * NFR * 64;
+        uint4* xn = s_x + static_cast<size_t>(par ^ 1) * NFR * 64;
+#pragma unroll
+        for (int slab = 0; slab < NB; ++slab) {
+            const int c = slab / 3, dy = slab % 3;
+            half8 (&w)[2][3] = (slab & 1) ? wB : wA;
+            half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
+            load_w(slab + 1, wn);
+            if (slab == 1 && yi < y1) stage(yi + 1, xn);
+            const int yo = yi + 1 - dy;
+            if (yo >= yb && yo < ye) {   // (uniform)
+                half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
+                half8 xl = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 1) * 64 + lane]);
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    half8 nh = xh, nl = xl;
+                    if (j + 1 < NX) {
+                        nh = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + 0) * 64 + lane]);
+                        nl = __builtin_bit_cast(half8, xs[(((j + 1) * NCI + c) * NSP + 1) * 64 + lane]);
+                    }
+#pragma unroll
+                    for (int pr = 0; pr < NPR; ++pr) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int i = HALO ? j - dx : j - dx + 1;   // output cell of the tile fed through tap column dx
+                            if (i < 0 || i >= XT) continue;
+                            const half8 wv = FIRST ? wres[pr == 1 ? 1 : 0][FIRST ? dy * 3 + dx : 0] : w[pr == 1 ? 1 : 0][dx];
+                            acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, pr == 2 ? xl : xh, acc[2 - dy][i], 0, 0, 0);
+                        }
+                    }
+                    xh = nh;
+                    xl = nl;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (yi - 1 >= yb) epilogue(yi - 1);
+#pragma unroll
+        for (int i = 0; i < XT; ++i) {
+            acc[0][i] = acc[1][i];
+            acc[1][i] = acc[2][i];
+            acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (ye == BW) epilogue(BW - 1);
+}
+
+struct LayerHArgs {
+    const void* src;   // fp32 plane batch (conv1) or split-fp16 activations
+    uint4* dst;
+    TrunkHLayer layer;
+    int res, nch;
+};
+
+template <int BW, int XT, int NC32, bool FIRST>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
+    constexpr int A = BW * BW;
+    constexpr int NXT = (BW + XT - 1) / XT;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];
+    const int xt = blockIdx.x % NXT;
+    const int rest = blockIdx.x / NXT;
+    const int grp = rest / a.nch, ch = rest - grp * a.nch;
+    const int base = BW / a.nch, extra = BW % a.nch;
+    const int yb = ch * base + (ch < extra ? ch : extra);
+    const int ye = yb + base + (ch < extra ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    uint4* dst = a.dst + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
+    if (FIRST) {
+        trunk_h_layer_tile<BW, XT, NC32, 1, true>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
+                                                  false, s_x, tile, lane, xt * XT, yb, ye);
+    } else {
+        trunk_h_layer_tile<BW, XT, NC32, NC32, false>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
+                                                      a.layer, a.res != 0, s_x, tile, lane, xt * XT, yb, ye);
+    }
+}
+
+template <int BW, int NC32>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
+    constexpr int A = BW * BW;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][row fragments][64] uint4
+    const int grp = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
+    // first activation fragment of this group (AO_KO 5 / 6: groups share buffers, timing experiment only)
+    const size_t gfrag = static_cast<size_t>(AO_KO == 5 ? grp % 64 : AO_KO == 6 ? grp % 128 : grp) * A * NC32 * 2;
+    uint4* bufA = a.bufA + gfrag * 64;
+    uint4* bufB = a.bufB + gfrag * 64;
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* pp = prof;
+    // conv1: fp32 planes -> x
+    AO_T(t0);
+    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp);
+    AO_T(t1);
+#ifdef AO_PROF
+    for (int k = 0; k < 12; ++k) prof[k] = 0;
+#endif
+    for (int l = 1; l < a.nlayers; ++l) {
+        // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
+        const bool second = (l & 1) == 0;
+        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp);
+    }
+    AO_T(t2);
+    trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
+#ifdef AO_PROF
+    AO_T(t3);
+    prof[5] = t3 - t2;
+    prof[6] = t1 - t0;
+    prof[7] = t3 - t0;
+    if (grp == 5 && lane == 0)
+        for (int k = 0; k < 12; ++k) ao_prof[tile * 12 + k] = prof[k];
+#endif
+}
+
+}  // namespace ao
