@@ -302,3 +302,50 @@ def load_data(model_path, dataset_path):
             rep_memory.extend(loaded)
         else:
             rep_memory = deque(loaded, maxlen=MEMORY_SIZE)
+
+
+def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, save_every=100, directory='data'):
+    """The reference's top-level loop (main.py:377-414): iteration 0 fills the replay memory with
+    N_SELFPLAY games; every later iteration plays ONE game and trains N_EPOCHS on it; model and
+    dataset are saved when n_iter % save_every == 0 (named n_iter + save_every, as the reference does);
+    result / cur_memory are reset after every iteration. Returns the number of iterations run."""
+    from datetime import datetime
+    if Agent is None:
+        configure()
+    load_data(model_path, dataset_path)
+    total_iter = TOTAL_ITER if total_iter is None else total_iter
+    n_first = N_SELFPLAY if n_selfplay is None else n_selfplay
+    done = 0
+    for n_iter in range(start_iter, total_iter):
+        logging.warning(datetime.now().isoformat())
+        logging.warning('=' * 58)
+        logging.warning(' ' * 20 + '  {:2} Iteration  '.format(n_iter) + ' ' * 20)
+        logging.warning('=' * 58)
+        if n_iter > 0:
+            self_play(1)
+            train(N_EPOCHS, n_iter)
+        else:
+            self_play(n_first)
+        if n_iter % save_every == 0 and parallel.world()[0] == 0:
+            save_model(Agent, n_iter + save_every, step, directory)
+            save_dataset(rep_memory, n_iter + save_every, step, directory)
+        reset_iter(result, cur_memory)
+        done += 1
+    return done
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser(description="self-play + training loop of the reference's main.py on the MI355X engine")
+    ap.add_argument('--board', type=int, default=BOARD_SIZE)
+    ap.add_argument('--sims', type=int, default=N_MCTS)
+    ap.add_argument('--blocks', type=int, default=N_BLOCKS)
+    ap.add_argument('--iters', type=int, default=TOTAL_ITER)
+    ap.add_argument('--selfplay', type=int, default=N_SELFPLAY, help='games of iteration 0')
+    ap.add_argument('--model', default=None)
+    ap.add_argument('--dataset', default=None)
+    ap.add_argument('--device-replay', action='store_true')
+    a = ap.parse_args()
+    parallel.init_from_env()
+    configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, device_replay=a.device_replay)
+    run(a.iters, a.model, a.dataset, a.selfplay)

@@ -169,3 +169,27 @@ def test_head_to_head_two_agents_match_oracle(oracle):
     assert win == oracle.check_win(oracle.get_board(list(root)[1:], B), 5)
     pe, ee = evaluate.elo(1500.0, 1500.0, 1.0, 0.0)
     assert abs(pe - 1516.0) < 1e-9 and abs(ee - 1484.0) < 1e-9
+
+
+def test_run_loop_iterations_save_and_train(tmp_path):
+    """main.run = the reference's __main__ loop (main.py:377-414): iteration 0 only plays, later
+    iterations play one game and train on it; checkpoints appear when n_iter % save_every == 0 and
+    load_data resumes from their file names."""
+    import os
+    from alpha_omok_amd import main
+    main.configure(board_size=9, n_mcts=8, n_blocks=1, seed=3)
+    main.rep_memory.clear(); main.cur_memory.clear()
+    main.step = 0; main.start_iter = 0
+    n = main.run(total_iter=3, n_selfplay=4, save_every=2, directory=str(tmp_path))
+    assert n == 3
+    assert main.step > 0                                   # iterations 1 and 2 trained
+    assert len(main.cur_memory) == 0 and main.result == {'Black': 0, 'White': 0, 'Draw': 0}
+    files = sorted(os.listdir(tmp_path))
+    models = [f for f in files if f.endswith('_step_model.pickle')]
+    datasets = [f for f in files if f.endswith('_step_dataset.pickle')]
+    assert len(models) == 2 and len(datasets) == 2         # n_iter 0 and 2, named 2 and 4
+    assert {int(f.split('_')[1]) for f in models} == {2, 4}
+    last = [f for f in models if f.split('_')[1] == '4'][0]
+    main.load_data(os.path.join(str(tmp_path), last), os.path.join(str(tmp_path), last.replace('model', 'dataset')))
+    assert main.start_iter == 5 and main.step == int(last.split('_')[2])
+    assert len(main.rep_memory) > 0
