@@ -195,3 +195,43 @@ def test_split_fp16_forward_takes_arbitrary_float_planes(B, batch):
     assert np.abs(p.cpu().numpy()[idx] - rp.numpy()).max() < TOL
     assert np.abs(v.cpu().numpy()[idx] - rv.numpy()).max() < TOL
     net.close()
+
+
+@pytest.mark.parametrize("mode,rounds", [(5, 1200), (2, 400)])
+def test_resident_trunk_stress_alternating_inputs(mode, rounds):
+    """The group-resident kernels hand a group's activations from layer to layer through HBM/L2 with only a
+    workgroup barrier + workgroup-scope acquire in between (the group is private to one workgroup, whose waves
+    share one L1). A stale line would be a timing-dependent error, so: 8 different 4096-board inputs in random
+    order, `rounds` forwards back to back under full load; every result must equal the first result of the same
+    input bit for bit, and those agree with the per-layer fp32 path (mode 4: one launch per layer, no in-kernel
+    hand-off) to fp32 accuracy."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    nb, B, planes, batch = 4, 9, 128, 4096
+    torch.manual_seed(11)
+    ref = PVNet(nb, 5, planes, B).eval()
+    net = ref.to_native(0)
+    rs = np.random.RandomState(5)
+    xs = [torch.from_numpy((rs.rand(batch, 5, B, B) < (0.1 + 0.1 * k)).astype(np.float32)).cuda() for k in range(8)]
+    net.set_mode(4)
+    want = []
+    for x in xs:
+        p, v = net(x)
+        torch.cuda.synchronize()
+        want.append((p.clone(), v.clone()))
+    net.set_mode(mode)
+    first = [None] * len(xs)
+    order = rs.randint(0, len(xs), size=rounds)
+    bad = 0
+    for it, k in enumerate(order):
+        p, v = net(xs[k])
+        if first[k] is None:
+            torch.cuda.synchronize()
+            first[k] = (p.clone(), v.clone())
+            assert (p - want[k][0]).abs().max().item() < 2e-5 and (v - want[k][1]).abs().max().item() < 2e-5, k
+        else:
+            if not (torch.equal(p, first[k][0]) and torch.equal(v, first[k][1])):
+                bad += 1
+    torch.cuda.synchronize()
+    assert bad == 0, "%d of %d forwards differed from the first result of the same input" % (bad, rounds)
+    net.close()
