@@ -59,7 +59,7 @@ __device__ unsigned long long ao_prof[8 * 12];
 // Knock-out switches for timing experiments (-DAO_KO=n together with -DAO_PROF; RESULTS ARE WRONG for n != 0, the
 // default build has AO_KO = 0 and every condition below folds away): 1 weights loaded for the first slabs only,
 // 2 LDS operand fragments read once per slab, 3 no staging of input rows, 4 no row epilogues (residual loads +
-// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint. Measured: profiles/r1j_trunk16h_phase_timing.txt
+// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint, 8 no heads. Measured: profiles/r1j_trunk16h_phase_timing.txt
 #ifndef AO_KO
 #define AO_KO 0
 #endif
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
         trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp);
     }
     AO_T(t2);
-    trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
+    if (AO_KO != 8) trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
 #ifdef AO_PROF
     AO_T(t3);
     prof[5] = t3 - t2;
