@@ -109,6 +109,62 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
                        "PVNet at batch 1, %d threads, %.1f s" % (moves, sims, cores, dt))
 
 
+def cpu_worker(board, sims, n_block, planes, sd_path, budget_s):
+    """One single-threaded CPU process of the all-cores baseline: independent games, torch at 1 thread."""
+    torch.set_num_threads(1)
+    from alpha_omok_amd.pvnet import PVNet
+    from oracle import oracle_py as O
+    net = PVNet(n_block, 5, planes, board)
+    net.load_state_dict(torch.load(sd_path))
+    net.eval()
+
+    def ev(moves, planes_, sim):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(planes_[None].copy()))
+        return p[0].numpy(), np.float32(v[0].item())
+
+    ag = O.Agent(board, sims, 5, noise=True, evaluator=ev)
+    ag.seed(os.getpid() & 0xffff)
+    root = (0,)
+    ag.get_pi(root, 1)  # warm-up, not timed
+    t0 = time.perf_counter()
+    moves = 0
+    while time.perf_counter() - t0 < budget_s:
+        pi, vis, pol = ag.get_pi(root, 1 if len(root) <= 6 else 0)
+        root = root + (int(ag.rng.choice_p(pi)),)
+        moves += 1
+        if O.check_win(O.get_board(list(root)[1:], board), 3 if board == 3 else 5) != 0:
+            ag.reset()
+            root = (0,)
+    print(json.dumps({"moves": moves, "seconds": time.perf_counter() - t0}))
+
+
+def cpu_all_cores(board, sims, n_block, planes, state_dict, budget_s):
+    """the fair all-cores CPU number -- one single-threaded process per core, independent games."""
+    import subprocess
+    import tempfile
+    procs_n = os.cpu_count() or 1
+    with tempfile.TemporaryDirectory() as d:
+        sd_path = os.path.join(d, "sd.pt")
+        torch.save(state_dict, sd_path)
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", sd_path, "--board", str(board), "--sims", str(sims),
+               "--blocks", str(n_block), "--planes", str(planes), "--cpu-budget", str(budget_s)]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for _ in range(procs_n)]
+        rate = 0.0
+        ok = 0
+        for pr in procs:
+            out, _ = pr.communicate()
+            try:
+                r = json.loads(out.decode().strip().splitlines()[-1])
+                rate += r["moves"] / r["seconds"]
+                ok += 1
+            except Exception:
+                pass
+    return dict(value=rate, unit="move-decisions/s", processes=ok, threads_per_process=1,
+                sample="%d independent single-threaded games for %.0f s each" % (ok, budget_s))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +182,13 @@ def main():
                     help="0 auto, 1 layer kernels, 2 group-resident fp32-MFMA trunk, 3 per-board, 4 row-chunked, "
                          "5 group-resident split-fp16 trunk")
     ap.add_argument("--no-fp32-compare", action="store_true", help="skip the extra fp32-MFMA-trunk measurement")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time one single-threaded CPU process per core (adds cpu_baseline.all_cores; ~40 s)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.board, args.sims, args.blocks, args.planes, args.cpu_worker, args.cpu_budget)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -327,6 +389,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, S, args.blocks, args.planes, sd, args.cpu_budget)
+                if args.cpu_all_cores:
+                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(B, S, args.blocks, args.planes, sd, args.cpu_budget)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "move-decisions/s", "cores": None,
                                        "kind": "port", "sample": "failed: %r" % (e,)}
