@@ -78,6 +78,13 @@ if dom:
     if row and row[1] and mfma:
         tj["avg_launch_ns"] = row[1]
         tj["mfma_busy_fraction"] = mfma / (1024.0 * row[1] * 2.4)
+    # the same against the cycles the kernel really ran (GRBM_GUI_ACTIVE is summed over the 8 XCDs): the clock
+    # drops under the power limit, so this is the pipe utilisation proper
+    gui = vals.get((k, "GRBM_GUI_ACTIVE"))
+    if gui and mfma:
+        tj["mfma_busy_fraction_of_cycles"] = mfma / (1024.0 * gui / 8.0)
+        if row and row[1]:
+            tj["effective_clock_ghz"] = (gui / 8.0) / row[1]
     tj["sq_valu_mfma_busy_cycles"] = mfma
     tj["sq_busy_cycles"] = busy
     tj["grbm_gui_active"] = vals.get((k, "GRBM_GUI_ACTIVE"))
