@@ -68,7 +68,11 @@ __device__ unsigned long long ao_prof[8 * 12];
 #endif
 template <int BW, int NC32, int NCI, bool FIRST>
 __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
-                                              int tile, int lane, unsigned long long* prof) {
+                                              int tile, int lane, unsigned long long* prof, const bool flip) {
+    // flip: this layer walks the board from the LAST row to the first (logical row y = physical row BW-1-y, tap rows
+    // mirrored). Layers alternate direction, so a layer starts with the rows the previous one wrote last -- still in
+    // L2 / the Infinity Cache -- instead of the ones that left the caches 340 MB of traffic ago.
+    auto py = [&](int y) { return flip ? BW - 1 - y : y; };
     constexpr int A = BW * BW;
     constexpr int NT = NC32 * 2;             // 16-channel output tiles = waves (two per SIMD at 128 channels)
     constexpr int NSP = 2;                   // halves of an input fragment
@@ -95,7 +99,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
         const int c = (slab / 3) % NCI, dy = slab % 3;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+            const int ub = ((((flip ? 2 - dy : dy) * 3 + dx) * NCI + c) * NT + tile) * 1024;
             W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
             W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
         }
@@ -139,7 +143,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     const int i = i0 + k < BW ? i0 + k : BW - 1;
-                    const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                    const int ob = (((py(yo) * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
                     rh[k] = buf_ld_h4(rs_dst, out_voff, ob);
                     rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
                 }
@@ -150,7 +154,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
                 if (i >= BW) continue;
                 const f32x4 c = acc[0][i];
                 float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
-                const int ob = (((yo * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                const int ob = (((py(yo) * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
                 if (RES) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
@@ -188,7 +192,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             const int f = tile + NT * k;
             if (f < NFR)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
-                                                         f * 1024, 0, 0);
+                                                         (py(0) * NFR + f) * 1024, 0, 0);
         }
     }
     AO_T(t_a2);
@@ -224,7 +228,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
                         if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
                         else
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
-                                                                     16, lane16, (yn * NFR + f) * 1024, 0, 0);
+                                                                     16, lane16, (py(yn) * NFR + f) * 1024, 0, 0);
                     }
                 }
             }
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     unsigned long long* pp = prof;
     // conv1: fp32 planes -> x
     AO_T(t0);
-    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp);
+    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false);
     AO_T(t1);
 #ifdef AO_PROF
     for (int k = 0; k < 12; ++k) prof[k] = 0;
@@ -510,7 +514,8 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     for (int l = 1; l < a.nlayers; ++l) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
-        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp);
+        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
+                                             (l & 1) != 0);
     }
     AO_T(t2);
     if (AO_KO != 8) trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
