@@ -41,15 +41,21 @@ __global__ __launch_bounds__(64) void k_expand_backup(TreeParams p) {
 // launch: the fused search loop (ao_search) is select | net | expand_select | net | ... -- one
 // launch fewer per simulation, which matters when a handful of games make every kernel a few
 // microseconds long. The trailing selection idles by itself once a game has all its simulations.
+// kGamesPerWG games per workgroup (one wave each, nothing shared between them): a quarter of the workgroups to
+// dispatch at 4096 games.
+constexpr int kGamesPerWG = 4;
 template <int NCH>
-__global__ __launch_bounds__(64) void k_expand_select(TreeParams p) {
-    __shared__ uint32_t s_mt[624];
-    __shared__ uint8_t s_ord[256];
-    __shared__ double s_prior[256];
-    __shared__ int16_t s_tab[256];
-    expand_backup_game<NCH>(p, blockIdx.x, s_ord, s_prior, s_tab);
+__global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p) {
+    __shared__ uint32_t s_mt[kGamesPerWG][624];
+    __shared__ uint8_t s_ord[kGamesPerWG][256];
+    __shared__ double s_prior[kGamesPerWG][256];
+    __shared__ int16_t s_tab[kGamesPerWG][256];
+    const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int g = blockIdx.x * kGamesPerWG + w;
+    if (g >= p.G) return;
+    expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w]);
     wsync();
-    select_game<NCH>(p, blockIdx.x, s_mt);
+    select_game<NCH>(p, g, s_mt[w]);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -377,7 +383,7 @@ void launch_expand_backup(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_backup<NCH>, dim3(p.G), dim3(64), 0, s, p));
 }
 void launch_expand_select(const TreeParams& p, hipStream_t s) {
-    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_select<NCH>, dim3(p.G), dim3(64), 0, s, p));
+    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_select<NCH>, dim3((p.G + kGamesPerWG - 1) / kGamesPerWG), dim3(64 * kGamesPerWG), 0, s, p));
 }
 void launch_begin_move(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_begin_move<NCH>, dim3(p.G), dim3(64), 0, s, p));
