@@ -5,6 +5,8 @@
   * anything else callable as model(x[G,C,B,B]) -> (policy[G,A], value[G]) -> stepwise protocol,
     one call per simulation on the whole leaf batch.
 """
+import weakref
+
 import numpy as np
 
 from . import pvnet
@@ -14,6 +16,8 @@ class Evaluator:
     def __init__(self, device=0):
         self.device = device
         self._key = None
+        self._ref = None
+        self._cfg = None
         self._net = None
         self._bufs = None
 
@@ -21,15 +25,31 @@ class Evaluator:
         cfg = pvnet.looks_like_pvnet(model)
         if cfg is None or cfg[2] % 32 or cfg[2] > 128 or cfg[3] != board_size or cfg[1] != inplanes:
             return None
-        version = sum(int(getattr(p, "_version", 0)) for p in model.state_dict().values())
-        key = (id(model), version)
-        if self._key != key:
+        # the native copy is keyed on the module OBJECT (held through a weak reference: a new module
+        # at a recycled address is a different object), its shape and the in-place version counters of
+        # its tensors; invalidate() forces a re-export for anything those cannot see
+        version = tuple(int(getattr(p, "_version", 0)) for p in model.state_dict().values())
+        same_module = self._ref is not None and self._ref() is model
+        if not same_module or self._key != (cfg, version):
             from .engine import Net
-            if self._net is None or self._key is None or self._key[0] != key[0]:
+            if self._net is None or self._cfg != cfg:
+                if self._net is not None:
+                    self._net.close()
                 self._net = Net(cfg[0], cfg[1], cfg[2], cfg[3], self.device)
+                self._cfg = cfg
             self._net.load_state_dict(model.state_dict())
-            self._key = key
+            self._key = (cfg, version)
+            try:
+                self._ref = weakref.ref(model)
+            except TypeError:
+                self._ref = None
         return self._net
+
+    def invalidate(self):
+        """Forget the exported weights: the next search re-exports Agent.model (called by main.train and
+        main.load_data; call it after replacing parameters in a way torch's version counters miss)."""
+        self._key = None
+        self._ref = None
 
     @staticmethod
     def _model_device(model):

@@ -13,8 +13,9 @@ Differences by design:
     refilled) instead of one after another. Episode e gets its own np.random stream seeded
     SEED + e (the reference draws all games from one stream); with n == 1 the process-global
     np.random state is used, which reproduces `np.random.seed(s); main.self_play(1)` exactly.
-  * under torch.distributed (one process per GPU) episodes are sharded e % world == rank and
-    train() all-reduces the flattened gradient (parallel.py).
+  * under torch.distributed (one process per GPU) episodes are sharded e % world == rank, train()
+    agrees on the mini-batch count and all-reduces the flattened gradient once per mini-batch
+    (parallel.py), and run() plays one game PER RANK in the iterations after the first.
   * configure(device_replay=True) keeps rep_memory in HBM (replay.DeviceReplay): the eight
     symmetries are made by a HIP kernel and train() gathers its mini-batches on the device. The
     entries, their order and the batches drawn under a given `random` state are the reference's.
@@ -122,7 +123,10 @@ def self_play(n_selfplay, seeds=None):
         Agent.model.eval()
     rank, world = parallel.world()
     episodes = parallel.shard_games(n_selfplay, rank, world)
+    first_episode = _episodes_played
+    _episodes_played += n_selfplay                        # identical on every rank, shard or no shard
     if not episodes:
+        Agent.reset()
         return
     use_global = (n_selfplay == 1 and seeds is None and world == 1)
     G = min(len(episodes), MAX_CONCURRENT)
@@ -130,7 +134,7 @@ def self_play(n_selfplay, seeds=None):
     eng.reset()
 
     def seed_of(ep):
-        return int(seeds[ep]) if seeds is not None else (SEED + _episodes_played + ep) & 0xFFFFFFFF
+        return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
 
     slot_ep = np.full(G, -1, np.int64)
     queue = list(episodes)
@@ -194,7 +198,6 @@ def self_play(n_selfplay, seeds=None):
             state = utils.get_state_pt(root, BOARD_SIZE, IN_PLANES)
             cur_memory.append((state, p, reward_black if t % 2 == 0 else reward_white))
             root = root + (a,)
-    _episodes_played += n_selfplay
     Agent.reset()
     if hasattr(rep_memory, "extend_augmented"):
         rep_memory.extend_augmented(cur_memory)           # symmetries made on the device
@@ -204,42 +207,70 @@ def self_play(n_selfplay, seeds=None):
 
 def train(n_epochs, n_iter):
     """One pass over 32*len(cur_memory) samples of rep_memory, batch 32, loss = MSE(v, z) +
-    CE(pi, p), Adam (main.py:253-336). Under torch.distributed every rank draws its own batch and
-    the gradients are averaged with one all-reduce per mini-batch before optimizer.step()."""
+    CE(pi, p), Adam (main.py:253-336). With one process this is the reference's pass, error
+    behaviour included: random.sample raises ValueError when rep_memory holds fewer than
+    32*len(cur_memory) entries (main.py:263-264).
+
+    Under torch.distributed (one process per GPU, rank-local cur_memory / rep_memory) it is the
+    data-parallel form of the same pass. The ranks first agree on the number of mini-batches --
+    ceil(sum over ranks of len(cur_memory) / world), so every new sample still buys 32 replay draws in
+    total -- then every rank draws that many batches of 32 from its OWN replay shard and each step
+    is: local forward/backward, ONE all-reduce of the flattened gradient, identical Adam step
+    everywhere. A rank whose shard is too small for a step (or empty) adds zeros and is left out of
+    the divisor, so every rank issues exactly the same collectives and the weights stay bit-identical
+    across ranks; the BatchNorm running statistics are averaged once at the end of the pass."""
     global step, total_epoch
     import torch
+    rank, world = parallel.world()
     Agent.model.train()
-    n = min(BATCH_SIZE * len(cur_memory), len(rep_memory))
     on_device = hasattr(rep_memory, "batch")
+    if world == 1:
+        n_steps = len(cur_memory)
+        n = BATCH_SIZE * n_steps
+    else:
+        n_steps = -(-parallel.agree(len(cur_memory), "sum", device) // world)
+        n = min(BATCH_SIZE * n_steps, len(rep_memory))
     # random.sample picks POSITIONS: sampling range(len) draws the same entries, with the same
     # consumption of the `random` stream, as sampling the sequence itself
     train_memory = random.sample(range(len(rep_memory)), n) if on_device else random.sample(list(rep_memory), n)
+    logging.warning('current memory size: {}'.format(len(cur_memory)))
+    logging.warning('replay memory size: {}'.format(len(rep_memory)))
+    logging.warning('train memory size: {}'.format(len(train_memory)))
     losses = []
+    trained = False
     for epoch in range(n_epochs):
-        for i in range(0, len(train_memory), BATCH_SIZE):
-            batch = train_memory[i:i + BATCH_SIZE]
-            if on_device:
-                s_batch, pi_batch, z_batch = rep_memory.batch(batch)
-            else:
-                s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
-                pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
-                z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
-            p_batch, v_batch = Agent.model(s_batch)
-            v_loss = (v_batch - z_batch).pow(2).mean()
-            p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
-            loss = v_loss + p_loss
+        for i in range(n_steps):
+            batch = train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]
             optimizer.zero_grad()
-            loss.backward()
-            parallel.allreduce_gradients(Agent.model)
+            if len(batch) > 0:
+                if on_device:
+                    s_batch, pi_batch, z_batch = rep_memory.batch(batch)
+                else:
+                    s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
+                    pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
+                    z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
+                p_batch, v_batch = Agent.model(s_batch)
+                v_loss = (v_batch - z_batch).pow(2).mean()
+                p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
+                loss = v_loss + p_loss
+                loss.backward()
+                trained = True
+            _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0)
+            if contributors == 0:
+                continue
             optimizer.step()
             step += 1
-            losses.append((loss.item(), v_loss.item(), p_loss.item()))
-            if PRINT_SELFPLAY:
-                print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *losses[-1]))
+            if len(batch) > 0:
+                losses.append((loss.item(), v_loss.item(), p_loss.item()))
+                if PRINT_SELFPLAY:
+                    print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *losses[-1]))
         total_epoch += 1
         if losses:
             m = np.mean(np.array(losses), axis=0)
             logging.warning('{:2} Epoch Loss: {:.4f}   Loss_V: {:.4f}   Loss_P: {:.4f}'.format(total_epoch, *m))
+    parallel.average_buffers(Agent.model, contributes=trained)
+    if _evaluator is not None:
+        _evaluator.invalidate()                           # the native copy of the weights is stale now
     return losses
 
 
@@ -291,6 +322,8 @@ def load_data(model_path, dataset_path):
         state = Agent.model.state_dict()
         state.update(torch.load(model_path, map_location=device))
         Agent.model.load_state_dict(state)
+        if _evaluator is not None:
+            _evaluator.invalidate()
         name = os.path.basename(model_path)
         step = int(name.split('_')[2])
         start_iter = int(name.split('_')[1]) + 1
@@ -306,7 +339,8 @@ def load_data(model_path, dataset_path):
 
 def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, save_every=100, directory='data'):
     """The reference's top-level loop (main.py:377-414): iteration 0 fills the replay memory with
-    N_SELFPLAY games; every later iteration plays ONE game and trains N_EPOCHS on it; model and
+    N_SELFPLAY games; every later iteration plays ONE game (per rank: `world` games under
+    torch.distributed, so no GPU idles) and trains N_EPOCHS on it; model and
     dataset are saved when n_iter % save_every == 0 (named n_iter + save_every, as the reference does);
     result / cur_memory are reset after every iteration. Returns the number of iterations run."""
     from datetime import datetime
@@ -322,7 +356,7 @@ def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, sa
         logging.warning(' ' * 20 + '  {:2} Iteration  '.format(n_iter) + ' ' * 20)
         logging.warning('=' * 58)
         if n_iter > 0:
-            self_play(1)
+            self_play(parallel.world()[1])                # the reference's one game -- on every GPU
             train(N_EPOCHS, n_iter)
         else:
             self_play(n_first)

@@ -49,7 +49,10 @@ def broadcast_parameters(module, src=0):
         return
     tensors = [t for t in module.state_dict().values() if t.is_floating_point()]
     flat = torch.cat([t.detach().reshape(-1) for t in tensors])
-    dist.broadcast(flat, src=src)
+    buf = _staged(flat)
+    dist.broadcast(buf, src=src)
+    if buf is not flat:
+        flat.copy_(buf)
     off = 0
     with torch.no_grad():
         for t in tensors:
@@ -58,19 +61,105 @@ def broadcast_parameters(module, src=0):
             off += k
 
 
-def allreduce_gradients(module):
-    """grad <- mean over ranks, through ONE flattened fp32 buffer (ncclAllReduce(sum) / world)."""
+def _staged(flat):
+    """The buffer a collective runs on: gloo works on host memory (two ranks may share one GPU in
+    the tests), nccl (= RCCL) on the device buffer itself."""
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo" and flat.is_cuda:
+        return flat.cpu()
+    return flat
+
+
+def agree(value, op="max", device=None):
+    """One integer every rank ends up with: max / min / sum of the ranks' local values. Used wherever a
+    later loop issues collectives, so that every rank runs the same number of them."""
     import torch.distributed as dist
     rank, n = world()
     if n == 1:
-        return 0
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(n)
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device or "cpu")
+    if dist.get_backend() == "nccl" and not t.is_cuda:
+        t = t.cuda()
+    dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+    return int(t.item())
+
+
+def allreduce_gradients(module, contributes=True):
+    """grad <- mean over the CONTRIBUTING ranks, through ONE flattened fp32 buffer (ncclAllReduce(sum)).
+
+    Every rank calls this once per mini-batch, whether or not it had a batch of its own: a rank without
+    one (empty replay shard, fewer samples than the agreed step count) passes contributes=False and adds
+    zeros. The last element of the buffer counts the contributors, so the divisor travels in the same
+    message. Returns (elements reduced, contributing ranks); with one process it is a no-op."""
+    import torch.distributed as dist
+    rank, n = world()
+    params = [p for p in module.parameters() if p.requires_grad]
+    if n == 1:
+        return sum(p.numel() for p in params), 1 if contributes else 0
+    dev = params[0].device
+    if contributes:
+        parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
+    else:
+        parts = [torch.zeros(p.numel(), dtype=p.dtype, device=dev) for p in params]
+    parts.append(torch.full((1,), 1.0 if contributes else 0.0, dtype=parts[0].dtype, device=dev))
+    flat = torch.cat(parts)
+    buf = _staged(flat)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if buf is not flat:
+        flat.copy_(buf)
+    count = int(round(float(flat[-1].item())))
+    if count > 0:
+        flat.div_(count)
     off = 0
-    for g in grads:
-        k = g.numel()
-        g.copy_(flat[off:off + k].view_as(g))
+    for p in params:
+        k = p.numel()
+        g = flat[off:off + k].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         off += k
-    return flat.numel()
+    return flat.numel() - 1, count
+
+
+def average_buffers(module, contributes=True):
+    """BatchNorm running statistics after a data-parallel training pass: every rank normalised its own
+    mini-batches, so running_mean / running_var differ; they are averaged over the ranks that trained
+    (one flattened all-reduce) and num_batches_tracked becomes the maximum, which leaves the state_dict
+    bit-identical on every rank (the gradients already were)."""
+    import torch.distributed as dist
+    rank, n = world()
+    if n == 1:
+        return
+    fl = [b for b in module.buffers() if b.is_floating_point()]
+    it = [b for b in module.buffers() if not b.is_floating_point()]
+    if fl:
+        dev = fl[0].device
+        parts = [(b.detach() if contributes else torch.zeros_like(b)).reshape(-1).float() for b in fl]
+        parts.append(torch.full((1,), 1.0 if contributes else 0.0, device=dev))
+        flat = torch.cat(parts)
+        buf = _staged(flat)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if buf is not flat:
+            flat.copy_(buf)
+        count = int(round(float(flat[-1].item())))
+        if count > 0:
+            flat.div_(count)
+            off = 0
+            with torch.no_grad():
+                for b in fl:
+                    k = b.numel()
+                    b.copy_(flat[off:off + k].view_as(b))
+                    off += k
+    if it:
+        flat = torch.cat([b.detach().reshape(-1).to(torch.int64) for b in it])
+        buf = _staged(flat)
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+        if buf is not flat:
+            flat.copy_(buf)
+        off = 0
+        with torch.no_grad():
+            for b in it:
+                k = b.numel()
+                b.copy_(flat[off:off + k].view_as(b))
+                off += k

@@ -180,7 +180,7 @@ def test_run_loop_iterations_save_and_train(tmp_path):
     main.configure(board_size=9, n_mcts=8, n_blocks=1, seed=3)
     main.rep_memory.clear(); main.cur_memory.clear()
     main.step = 0; main.start_iter = 0
-    n = main.run(total_iter=3, n_selfplay=4, save_every=2, directory=str(tmp_path))
+    n = main.run(total_iter=3, n_selfplay=12, save_every=2, directory=str(tmp_path))
     assert n == 3
     assert main.step > 0                                   # iterations 1 and 2 trained
     assert len(main.cur_memory) == 0 and main.result == {'Black': 0, 'White': 0, 'Draw': 0}

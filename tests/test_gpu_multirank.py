@@ -68,3 +68,51 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
                 assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
             seen.add(e)
     assert seen == set(range(EPISODES))
+
+
+def _run_worker(rank, world, port, out, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import random
+    from alpha_omok_amd import main, parallel
+    parallel.init_from_env("gloo")
+    torch.manual_seed(100 + rank)                      # configure() must broadcast rank 0's weights
+    main.configure(board_size=B, n_mcts=8, n_blocks=1, out_planes=32, seed=3, gpu=0)
+    random.seed(300 + rank)                            # rank-local replay draws
+    main.rep_memory.clear(); main.cur_memory.clear()
+    main.step = 0; main.start_iter = 0
+    lens = []
+    orig_train = main.train
+    def spy(n_epochs, n_iter):
+        lens.append(len(main.cur_memory))
+        return orig_train(n_epochs, n_iter)
+    main.train = spy
+    n = main.run(total_iter=3, n_selfplay=7, save_every=2, directory=tmp)
+    main.train = orig_train
+    sd = {k: v.detach().cpu().clone() for k, v in main.Agent.model.state_dict().items()}
+    torch.save(dict(n=n, step=main.step, sd=sd, lens=lens, rep=len(main.rep_memory)), out % rank)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_training_loop_without_deadlock(tmp_path):
+    """main.run (the reference's __main__ loop, main.py:377-414) under torch.distributed: iteration 0
+    shards 7 games 4 / 3, iterations 1 and 2 play one game per rank (different lengths) and train --
+    every rank runs the same number of optimiser steps (ceil(sum of new samples / world)), the
+    weights and BatchNorm buffers stay bit-identical across ranks, only rank 0 writes checkpoints."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "run%d.pt")
+    ck = tmp_path / "ck"
+    mp.spawn(_run_worker, args=(2, port, out, str(ck)), nprocs=2, join=True)
+    r0, r1 = (torch.load(out % r, weights_only=False) for r in range(2))
+    assert r0["n"] == r1["n"] == 3
+    assert len(r0["lens"]) == len(r1["lens"]) == 2
+    want_steps = sum(-(-(a + b) // 2) for a, b in zip(r0["lens"], r1["lens"]))
+    assert r0["step"] == r1["step"] == want_steps > 0
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    models = [f for f in os.listdir(ck) if f.endswith("_step_model.pickle")]
+    assert len(models) == 2                               # n_iter 0 and 2, written once (rank 0)

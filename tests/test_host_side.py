@@ -143,7 +143,8 @@ def _ddp_worker(rank, world, port, out):
     p, v = net(x[sl])
     loss = (v - z[sl]).pow(2).mean() - (pi[sl] * p.log()).sum(-1).mean()
     loss.backward()
-    n = parallel.allreduce_gradients(net)
+    n, contributors = parallel.allreduce_gradients(net)
+    assert contributors == world
     flat = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
     torch.save(dict(same=same, n=n, grad=flat, shard=parallel.shard_games(10, rank, world)), out % rank)
     dist.barrier()
@@ -175,6 +176,70 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     full = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
     assert r0["n"] == full.numel()
     assert (r0["grad"] - full).abs().max().item() < 1e-5
+
+
+def _train_worker(rank, world, port, out, n_cur, n_rep):
+    """main.train under torch.distributed with rank-local memories of DIFFERENT sizes (the round-1
+    deadlock: the mini-batch count was rank-local). n_cur / n_rep: per-rank len(cur_memory) /
+    len(rep_memory)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from alpha_omok_amd import main, parallel
+    from alpha_omok_amd.pvnet import PVNet
+    parallel.init_from_env("gloo")
+    torch.manual_seed(50 + rank)                       # different initial weights: configure() must broadcast
+    main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9))
+    rs = np.random.RandomState(100 + rank)
+    random.seed(200 + rank)                            # every rank draws its own batches
+    def sample():
+        return ((rs.rand(5, 9, 9) < 0.3).astype(np.float64), rs.dirichlet(np.ones(81)), float(rs.choice([-1, 0, 1])))
+    main.cur_memory.clear(); main.rep_memory.clear()
+    main.cur_memory.extend(sample() for _ in range(n_cur[rank]))
+    main.rep_memory.extend(sample() for _ in range(n_rep[rank]))
+    main.step = 0
+    losses = main.train(1, 1)
+    sd = {k: v.clone() for k, v in main.Agent.model.state_dict().items()}
+    torch.save(dict(sd=sd, step=main.step, n_losses=len(losses)), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cur,n_rep,steps,n_losses", [
+    ((3, 5), (400, 400), 4, (4, 4)),        # unequal new samples: ceil(8 / 2) steps on both ranks
+    ((6, 0), (150, 0), 3, (3, 0)),          # rank 1 holds nothing at all (run() with fewer games than ranks)
+    ((4, 4), (70, 400), 4, (3, 4)),         # rank 0's shard runs out after 2 full + 1 partial batch
+])
+def test_gloo_world2_train_with_unequal_memories(tmp_path, n_cur, n_rep, steps, n_losses):
+    """Every rank issues the same number of all-reduces whatever its local sample counts are, the
+    optimiser steps are identical and the state_dict (BatchNorm buffers included) ends bit-identical."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 29500 + random.randint(0, 2000)
+    out = str(tmp_path / "t%d.pt")
+    mp.spawn(_train_worker, args=(2, port, out, n_cur, n_rep), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0["step"] == r1["step"] == steps
+    assert (r0["n_losses"], r1["n_losses"]) == n_losses
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    assert int(r0["sd"]["bn1.num_batches_tracked"]) == max(n_losses)
+
+
+def test_train_raises_like_the_reference_when_replay_is_too_small():
+    """main.py:263-264: random.sample(rep_memory, 32 * len(cur_memory)) raises ValueError."""
+    from alpha_omok_amd import main
+    from alpha_omok_amd.pvnet import PVNet
+    main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9))
+    smp = (np.zeros((5, 9, 9)), np.ones(81) / 81, 1.0)
+    main.cur_memory.clear(); main.rep_memory.clear()
+    main.cur_memory.extend([smp] * 2)
+    main.rep_memory.extend([smp] * 63)
+    with pytest.raises(ValueError):
+        main.train(1, 1)
+    main.cur_memory.clear(); main.rep_memory.clear()
 
 
 def test_checkpoint_wire_format_roundtrip(tmp_path):
