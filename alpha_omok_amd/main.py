@@ -113,6 +113,14 @@ def _get_engine(games):
     return _engine
 
 
+def release_engine():
+    """Free the self-play engine's HBM (trees of MAX_CONCURRENT games); the next self_play() rebuilds it."""
+    global _engine
+    if _engine is not None:
+        _engine.close()
+        _engine = None
+
+
 def self_play(n_selfplay, seeds=None):
     """Plays n_selfplay episodes and appends their samples to cur_memory / rep_memory exactly as the
     reference does: per episode, plies in chronological order, (state [C,B,B] f64, pi [A] f64, z)."""
@@ -205,6 +213,38 @@ def self_play(n_selfplay, seeds=None):
         rep_memory.extend(utils.augment_dataset(cur_memory, BOARD_SIZE))
 
 
+def train_batch(batch):
+    """One optimiser step of main.py:283-305 on `batch` (entries of rep_memory, or positions in it when
+    rep_memory lives on the device; an EMPTY batch means this rank has nothing for this step and only
+    takes part in the collective). Local forward/backward, one all-reduce of the flattened gradient over
+    the ranks (none with one process), Adam step. Returns (loss, v_loss, p_loss) or None for an empty
+    batch; `step` advances whenever any rank contributed."""
+    global step
+    import torch
+    optimizer.zero_grad()
+    out = None
+    if len(batch) > 0:
+        if hasattr(rep_memory, "batch"):
+            s_batch, pi_batch, z_batch = rep_memory.batch(batch)
+        else:
+            s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
+            pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
+            z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
+        p_batch, v_batch = Agent.model(s_batch)
+        v_loss = (v_batch - z_batch).pow(2).mean()
+        p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
+        loss = v_loss + p_loss
+        loss.backward()
+    _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0)
+    if contributors == 0:
+        return None
+    optimizer.step()
+    step += 1
+    if len(batch) > 0:
+        out = (loss.item(), v_loss.item(), p_loss.item())
+    return out
+
+
 def train(n_epochs, n_iter):
     """One pass over 32*len(cur_memory) samples of rep_memory, batch 32, loss = MSE(v, z) +
     CE(pi, p), Adam (main.py:253-336). With one process this is the reference's pass, error
@@ -219,8 +259,7 @@ def train(n_epochs, n_iter):
     everywhere. A rank whose shard is too small for a step (or empty) adds zeros and is left out of
     the divisor, so every rank issues exactly the same collectives and the weights stay bit-identical
     across ranks; the BatchNorm running statistics are averaged once at the end of the pass."""
-    global step, total_epoch
-    import torch
+    global total_epoch
     rank, world = parallel.world()
     Agent.model.train()
     on_device = hasattr(rep_memory, "batch")
@@ -241,29 +280,12 @@ def train(n_epochs, n_iter):
     for epoch in range(n_epochs):
         for i in range(n_steps):
             batch = train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]
-            optimizer.zero_grad()
-            if len(batch) > 0:
-                if on_device:
-                    s_batch, pi_batch, z_batch = rep_memory.batch(batch)
-                else:
-                    s_batch = torch.tensor(np.stack([b[0] for b in batch])).to(device).float()
-                    pi_batch = torch.tensor(np.stack([b[1] for b in batch])).to(device).float()
-                    z_batch = torch.tensor(np.array([b[2] for b in batch])).to(device).float()
-                p_batch, v_batch = Agent.model(s_batch)
-                v_loss = (v_batch - z_batch).pow(2).mean()
-                p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
-                loss = v_loss + p_loss
-                loss.backward()
+            out = train_batch(batch)
+            if out is not None:
                 trained = True
-            _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0)
-            if contributors == 0:
-                continue
-            optimizer.step()
-            step += 1
-            if len(batch) > 0:
-                losses.append((loss.item(), v_loss.item(), p_loss.item()))
+                losses.append(out)
                 if PRINT_SELFPLAY:
-                    print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *losses[-1]))
+                    print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *out))
         total_epoch += 1
         if losses:
             m = np.mean(np.array(losses), axis=0)

@@ -57,6 +57,20 @@ def eval_flops(board, inplanes, planes, n_block):
                   2 * A * A + A * planes + A * planes + planes)
 
 
+def host_cpu():
+    """(hardware threads, CPU model string) of this host."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return os.cpu_count() or 1, model
+
+
 def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
     """Sequential reference-style search on the host CPU: oracle tree + torch-CPU net, batch 1."""
     from alpha_omok_amd.pvnet import PVNet
@@ -104,13 +118,17 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
             ag.reset()
             root = (0,)
     dt = time.perf_counter() - t0
-    return dict(value=moves / dt, unit="move-decisions/s", cores=cores, kind="port",
+    nproc, cpu_model = host_cpu()
+    return dict(value=moves / dt, unit="move-decisions/s", cores=cores, kind="port", host_nproc=nproc, host_cpu_model=cpu_model,
                 sample="%d move decisions of one 9x9 game, %d sims each, oracle C tree + PyTorch-CPU "
                        "PVNet at batch 1, %d threads, %.1f s" % (moves, sims, cores, dt))
 
 
 def cpu_worker(board, sims, n_block, planes, sd_path, budget_s):
-    """One single-threaded CPU process of the all-cores baseline: independent games, torch at 1 thread."""
+    """One single-threaded CPU process of the all-cores baseline: independent games, torch at 1 thread.
+    A 400-simulation move takes ~30 s on one thread of a loaded host, so the sample is counted in
+    SIMULATIONS (searches of `chunk` simulations from successive positions of a game) and scaled to
+    move decisions of `sims` simulations by the parent."""
     torch.set_num_threads(1)
     from alpha_omok_amd.pvnet import PVNet
     from oracle import oracle_py as O
@@ -123,20 +141,23 @@ def cpu_worker(board, sims, n_block, planes, sd_path, budget_s):
             p, v = net(torch.from_numpy(planes_[None].copy()))
         return p[0].numpy(), np.float32(v[0].item())
 
-    ag = O.Agent(board, sims, 5, noise=True, evaluator=ev)
+    chunk = min(sims, 40)
+    ag = O.Agent(board, chunk, 5, noise=True, evaluator=ev)
     ag.seed(os.getpid() & 0xffff)
     root = (0,)
-    ag.get_pi(root, 1)  # warm-up, not timed
+    warm = O.Agent(board, 4, 5, noise=True, evaluator=ev)
+    warm.seed(1)
+    warm.get_pi(root, 1)  # pages torch in; not timed
     t0 = time.perf_counter()
-    moves = 0
+    done = 0
     while time.perf_counter() - t0 < budget_s:
         pi, vis, pol = ag.get_pi(root, 1 if len(root) <= 6 else 0)
+        done += int(vis.sum()) if len(root) == 1 else chunk
         root = root + (int(ag.rng.choice_p(pi)),)
-        moves += 1
         if O.check_win(O.get_board(list(root)[1:], board), 3 if board == 3 else 5) != 0:
             ag.reset()
             root = (0,)
-    print(json.dumps({"moves": moves, "seconds": time.perf_counter() - t0}))
+    print(json.dumps({"sims": done, "seconds": time.perf_counter() - t0}))
 
 
 def cpu_all_cores(board, sims, n_block, planes, state_dict, budget_s):
@@ -157,12 +178,84 @@ def cpu_all_cores(board, sims, n_block, planes, state_dict, budget_s):
             out, _ = pr.communicate()
             try:
                 r = json.loads(out.decode().strip().splitlines()[-1])
-                rate += r["moves"] / r["seconds"]
+                rate += r["sims"] / float(sims) / r["seconds"]
                 ok += 1
             except Exception:
                 pass
     return dict(value=rate, unit="move-decisions/s", processes=ok, threads_per_process=1,
-                sample="%d independent single-threaded games for %.0f s each" % (ok, budget_s))
+                sample="%d independent single-threaded processes (one per hardware thread), each searching successive "
+                       "positions of its own game in chunks of %d simulations for %.0f s; simulations / %d = move decisions"
+                       % (ok, min(sims, 40), budget_s, sims))
+
+
+class TrainStep:
+    """BASELINE configs[3]'s training step beside the self-play: one mini-batch of 32 from the rank-local replay
+    shard (device-resident ring, filled before the timed region by real self-play games of this engine at a small
+    simulation count), the reference's loss and Adam step (alpha_omok_amd.main.train_batch = main.py:283-305), ONE
+    all-reduce of the flattened fp32 gradient over the ranks, then the updated weights are re-exported to the
+    native forward the search uses."""
+
+    def __init__(self, args, model, local, rank, world, net):
+        import random
+        from alpha_omok_amd import main as M
+        self.M, self.net, self.random, self.world = M, net, random, world
+        M.PRINT_SELFPLAY = False
+        M.configure(board_size=args.board, n_mcts=args.prefill_sims, n_blocks=args.blocks, out_planes=args.planes,
+                    seed=1000 + rank, model=model.to(torch.device("cuda", local)), gpu=local, device_replay=True)
+        M.rep_memory.clear()
+        M.cur_memory.clear()
+        M.self_play(args.prefill_games * world)   # episodes shard e % world == rank
+        M.cur_memory.clear()
+        M.release_engine()
+        random.seed(2000 + rank)
+        M.Agent.model.train()
+        self.numel = sum(p.numel() for p in M.Agent.model.parameters())
+        self.ms, self.export_ms, self.losses = [], [], []
+
+    def step(self, record):
+        M = self.M
+        t0 = time.perf_counter()
+        n = len(M.rep_memory)
+        batch = self.random.sample(range(n), min(M.BATCH_SIZE, n))
+        out = M.train_batch(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.net.load_state_dict(M.Agent.model.state_dict())
+        t2 = time.perf_counter()
+        if record:
+            self.ms.append((t1 - t0) * 1e3)
+            self.export_ms.append((t2 - t1) * 1e3)
+            if out is not None:
+                self.losses.append(out[0])
+
+    def allreduce_probe(self, dist, dev):
+        """Isolated cost of the step's collective: the same flattened buffer, 20 repetitions."""
+        if dist is None:
+            return None
+        flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        for _ in range(3):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 20 * 1e3
+
+    def report(self, dist, dev, ms_per_step):
+        M = self.M
+        r = {"workload": "one batch-%d training step per GPU after every step (refill cycle), rank-local replay shard, "
+                         "one all-reduce of the flattened gradient (BASELINE configs[3])" % M.BATCH_SIZE,
+             "train_steps": len(self.ms), "ms_per_train_step": float(np.mean(self.ms)) if self.ms else None,
+             "ms_weight_export": float(np.mean(self.export_ms)) if self.export_ms else None,
+             "allreduce_elements": self.numel + 1, "allreduce_bytes": 4 * (self.numel + 1),
+             "allreduce_backend": (dist.get_backend() if dist is not None else None), "allreduce_ranks": self.world,
+             "allreduce_ms_isolated": self.allreduce_probe(dist, dev),
+             "replay_entries_per_gpu": len(M.rep_memory), "mean_loss": float(np.mean(self.losses)) if self.losses else None,
+             "inside_timed_region": True}
+        if self.ms:
+            r["share_of_step"] = (float(np.mean(self.ms)) + float(np.mean(self.export_ms))) / ms_per_step
+        return r
 
 
 def main():
@@ -182,8 +275,15 @@ def main():
                     help="0 auto, 1 layer kernels, 2 group-resident fp32-MFMA trunk, 3 per-board, 4 row-chunked, "
                          "5 group-resident split-fp16 trunk")
     ap.add_argument("--no-fp32-compare", action="store_true", help="skip the extra fp32-MFMA-trunk measurement")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time one single-threaded CPU process per core (adds cpu_baseline.all_cores; ~40 s)")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="(kept for compatibility: the all-cores sample is on by default)")
+    ap.add_argument("--train-step", choices=("auto", "on", "off"), default="auto",
+                    help="BASELINE configs[3]: after every step (= refill cycle) one batch-32 training step per GPU "
+                         "from the rank-local replay shard with ONE all-reduce of the flattened gradient; "
+                         "auto = on when more than one GPU takes part")
+    ap.add_argument("--prefill-sims", type=int, default=16, help="simulations per move of the replay-filling games")
+    ap.add_argument("--prefill-games", type=int, default=48, help="self-play games per GPU that fill the replay shard (untimed)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-hardware-thread CPU sample")
+    ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0, help="seconds per process of the all-cores sample")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -247,8 +347,16 @@ def main():
                 next_seed[0] += world
             ply[done] = 0
 
+    train_on = args.train_step == "on" or (args.train_step == "auto" and world > 1)
+    trainer = TrainStep(args, model, local, rank, world, net) if train_on else None
+
+    def cycle(count):
+        step(count)
+        if trainer is not None:
+            trainer.step(count)
+
     for _ in range(args.warmup):
-        step(False)
+        cycle(False)
 
     def fence():
         eng.sync()
@@ -261,7 +369,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        cycle(True)
     fence()
     dt = time.perf_counter() - t0
     conv_ms, conv_launches = net.conv_timing(False)
@@ -272,6 +380,7 @@ def main():
     dt_max = float(t.item())
     total_moves = world * G * args.steps
     value = total_moves / dt_max
+    train_report = trainer.report(dist, dev, dt_max / args.steps * 1e3) if trainer is not None else None  # (collective)
 
     if rank == 0:
         kname, f_launch = net.dominant_kernel(G)
@@ -310,11 +419,14 @@ def main():
             "config": {
                 "workload": "%s: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "
                             "leaf batch %d, random-init %d-block/%d-ch PVNet" % (
+                                "BASELINE configs[3] (per-GPU shape of configs[2] + training step with gradient all-reduce)"
+                                if (B, G, S, args.blocks) == (9, 4096, 400, 4) and train_on else
                                 "BASELINE configs[2]" if (B, G, S, args.blocks) == (9, 4096, 400, 4) else
                                 "BASELINE configs[4] per-GPU shape" if (B, G, S, args.blocks) == (15, 1024, 800, 10) else
                                 "custom shape", B, B, G, S, G, args.blocks, args.planes),
                 "games_per_gpu": G, "sims": S, "board": B, "n_block": args.blocks, "planes": args.planes,
-                "parallelism": "games sharded over %d GPU(s), no data-path collective" % world,
+                "parallelism": "games sharded over %d GPU(s), no data-path collective in self-play%s" % (
+                    world, "; one gradient all-reduce per training step" if train_on else ""),
                 "mean_select_depth": counters["levels"] / sims_total,
                 "terminal_leaf_fraction": counters["terminal"] / sims_total,
                 "games_finished": counters["games"],
@@ -348,6 +460,8 @@ def main():
                 "conv_time_share": (conv_ms * 1e-3) / dt if dt > 0 else None,
             },
         }
+        if train_report is not None:
+            out["train_step"] = train_report
         if world == 1 and split16 and not args.no_fp32_compare:
             # the same workload with the fp32-MFMA trunk (k_trunk16), for comparison
             try:
@@ -389,8 +503,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, S, args.blocks, args.planes, sd, args.cpu_budget)
-                if args.cpu_all_cores:
-                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(B, S, args.blocks, args.planes, sd, args.cpu_budget)
+                if not args.no_cpu_all_cores:
+                    out["cpu_baseline"]["all_cores"] = cpu_all_cores(B, S, args.blocks, args.planes, sd,
+                                                                     args.cpu_all_cores_budget)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "move-decisions/s", "cores": None,
                                        "kind": "port", "sample": "failed: %r" % (e,)}
