@@ -50,6 +50,7 @@ SYMBOLS = {
     "ao_set_rng_state": (C.c_int, [_vp, C.c_int, _u32p, C.c_int32, C.c_int32, C.c_double]),
     "ao_reset": (C.c_int, [_vp, _u8p]),
     "ao_set_root": (C.c_int, [_vp, C.c_int, _i32p, C.c_int32, _i32p]),
+    "ao_set_roots": (C.c_int, [_vp, _u8p, _i32p, C.c_int32, _i32p, _i32p]),
     "ao_begin_move": (C.c_int, [_vp, _u8p]),
     "ao_sims_left": (C.c_int, [_vp]),
     "ao_collect_leaves": (C.c_int, [_vp, _vp]),

@@ -28,8 +28,8 @@ void launch_expand_select(const TreeParams& p, hipStream_t s);
 void launch_begin_move(const TreeParams& p, hipStream_t s);
 void launch_end_move(const TreeParams& p, hipStream_t s);
 void launch_play(const TreeParams& p, hipStream_t s);
-void launch_walk(const TreeParams& p, int g, const int32_t* extra, int m, int prev_known,
-                 int32_t* status_out, hipStream_t s);
+void launch_walk(const TreeParams& p, int count, const int32_t* games, const int32_t* extra, int stride, const int32_t* m,
+                 const int32_t* prev_known, int32_t* status_out, hipStream_t s);
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 // net.hip
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
@@ -50,7 +50,8 @@ struct ao_engine {
     std::vector<void*> allocs;
     // device scratch
     uint8_t* d_active = nullptr; int8_t* d_tau = nullptr; int32_t* d_extra = nullptr;
-    int32_t* d_status = nullptr; uint8_t* d_mask = nullptr;
+    uint8_t* d_mask = nullptr;
+    std::vector<int32_t> h_walk;     // staging of ao_set_root(s): [G][A] moves + games, counts, prev_known, status
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
     size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
@@ -169,7 +170,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &p.out_pi, static_cast<size_t>(G) * A) || dev_alloc(e, &p.out_visit, static_cast<size_t>(G) * A) ||
         dev_alloc(e, &p.out_policy, static_cast<size_t>(G) * A) || dev_alloc(e, &p.action, G) ||
         dev_alloc(e, &p.win, G) || dev_alloc(e, &e->d_active, G) || dev_alloc(e, &e->d_tau, G) ||
-        dev_alloc(e, &e->d_extra, A + 1) || dev_alloc(e, &e->d_status, 4) || dev_alloc(e, &e->d_mask, G))
+        dev_alloc(e, &e->d_extra, static_cast<size_t>(G) * A + 4 * static_cast<size_t>(G)) || dev_alloc(e, &e->d_mask, G))
         return 1;
     // evaluation batches of the native network: interleaved input, policy/value rows for Gp boards
     float* il = nullptr;
@@ -296,41 +297,98 @@ int ao_reset(ao_engine* e, const uint8_t* mask) {
     return 0;
 }
 
-int ao_set_root(ao_engine* e, int g, const int32_t* mv, int32_t n, int32_t* status) {
-    if (g < 0 || g >= e->G) return e->fail("game index out of range");
-    if (n < 0 || n > e->A) return e->fail("move list too long");
+// Walks the listed games along their new ids in ONE launch (k_walk: a workgroup per listed game).
+// ids[k] / ns[k]: full move list of games[k]. Games whose new id does not extend the kept one are reset first.
+static int set_roots_impl(ao_engine* e, int count, const int32_t* games, const int32_t* const* ids, const int32_t* ns,
+                          int32_t* status) {
     AO_HIP(e, hipSetDevice(e->cfg.device));
-    std::vector<int32_t>& cur = e->moves[g];
-    bool extends = static_cast<size_t>(n) >= cur.size() &&
-                   std::equal(cur.begin(), cur.end(), mv);
-    int first = 0;
-    int prev_known = (e->status[g] != AO_ROOT_FRESH) ? 1 : 0;
-    if (!extends) {
-        std::vector<uint8_t> mask(e->G, 0);
-        mask[g] = 1;
-        if (ao_reset(e, mask.data())) return 1;
-        prev_known = 0;
-    } else {
-        first = static_cast<int>(cur.size());
+    if (count <= 0) return 0;
+    const int G = e->G, A = e->A;
+    std::vector<uint8_t> seen(G, 0);
+    for (int k = 0; k < count; ++k) {
+        if (games[k] < 0 || games[k] >= G) return e->fail("game index out of range");
+        if (seen[games[k]]) return e->fail("ao_set_roots: a game is listed twice");
+        seen[games[k]] = 1;
+        if (ns[k] < 0 || ns[k] > A) return e->fail("move list too long");
     }
-    const int m = n - first;
-    if (m > 0)
-        AO_HIP(e, hipMemcpyAsync(e->d_extra, mv + first, sizeof(int32_t) * m, hipMemcpyHostToDevice, e->stream));
-    ao::launch_walk(e->tp, g, e->d_extra, m, prev_known, e->d_status, e->stream);
-    int32_t st = 0;
-    AO_HIP(e, hipMemcpyAsync(&st, e->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    // staging: [count][A] new moves, then games / counts / prev_known (device reads), then status (device writes)
+    e->h_walk.assign(static_cast<size_t>(count) * A + 4 * static_cast<size_t>(count), 0);
+    int32_t* h_extra = e->h_walk.data();
+    int32_t* h_games = h_extra + static_cast<size_t>(count) * A;
+    int32_t* h_m = h_games + count;
+    int32_t* h_pk = h_m + count;
+    std::vector<uint8_t> rmask;
+    for (int k = 0; k < count; ++k) {
+        const int g = games[k];
+        const std::vector<int32_t>& cur = e->moves[g];
+        const int n = ns[k];
+        const bool extends = static_cast<size_t>(n) >= cur.size() && std::equal(cur.begin(), cur.end(), ids[k]);
+        int first = 0;
+        int prev_known = (e->status[g] != AO_ROOT_FRESH) ? 1 : 0;
+        if (!extends) {
+            if (rmask.empty()) rmask.assign(G, 0);
+            rmask[g] = 1;
+            prev_known = 0;
+        } else {
+            first = static_cast<int>(cur.size());
+        }
+        h_games[k] = g;
+        h_m[k] = n - first;
+        h_pk[k] = prev_known;
+        std::copy(ids[k] + first, ids[k] + n, h_extra + static_cast<size_t>(k) * A);
+    }
+    if (!rmask.empty() && ao_reset(e, rmask.data())) return 1;
+    int32_t* d_games = e->d_extra + static_cast<size_t>(count) * A;
+    AO_HIP(e, hipMemcpyAsync(e->d_extra, h_extra, sizeof(int32_t) * (static_cast<size_t>(count) * A + 3 * static_cast<size_t>(count)),
+                             hipMemcpyHostToDevice, e->stream));
+    ao::launch_walk(e->tp, count, d_games, e->d_extra, A, d_games + count, d_games + 2 * count, d_games + 3 * count, e->stream);
+    AO_HIP(e, hipGetLastError());
+    int32_t* h_st = h_pk + count;
+    AO_HIP(e, hipMemcpyAsync(h_st, d_games + 3 * count, sizeof(int32_t) * count, hipMemcpyDeviceToHost, e->stream));
     AO_HIP(e, hipStreamSynchronize(e->stream));
-    if (st < 0) {
-        std::vector<uint8_t> mask(e->G, 0);
-        mask[g] = 1;
-        ao_reset(e, mask.data());
+    bool bad = false;
+    std::vector<uint8_t> bmask;
+    for (int k = 0; k < count; ++k) {
+        const int g = games[k];
+        if (h_st[k] < 0) {
+            if (bmask.empty()) bmask.assign(G, 0);
+            bmask[g] = 1;
+            bad = true;
+            if (status) status[k] = -1;
+            continue;
+        }
+        e->moves[g].assign(ids[k], ids[k] + ns[k]);
+        e->status[g] = h_st[k];
+        e->over[g] = 0;
+        if (status) status[k] = h_st[k];
+    }
+    if (bad) {
+        ao_reset(e, bmask.data());
         return e->fail("ao_set_root: illegal move in the id (occupied cell or out of range)");
     }
-    cur.assign(mv, mv + n);
-    e->status[g] = st;
-    e->over[g] = 0;
-    if (status) *status = st;
     return 0;
+}
+
+int ao_set_root(ao_engine* e, int g, const int32_t* mv, int32_t n, int32_t* status) {
+    return set_roots_impl(e, 1, &g, &mv, &n, status);
+}
+
+int ao_set_roots(ao_engine* e, const uint8_t* mask, const int32_t* moves, int32_t stride, const int32_t* n, int32_t* status) {
+    if (!moves || !n) return e->fail("ao_set_roots: null argument");
+    std::vector<int32_t> games, ns;
+    std::vector<const int32_t*> ids;
+    for (int g = 0; g < e->G; ++g) {
+        if (mask && !mask[g]) continue;
+        games.push_back(g);
+        ns.push_back(n[g]);
+        ids.push_back(moves + static_cast<size_t>(g) * stride);
+        if (n[g] > stride) return e->fail("ao_set_roots: n[g] exceeds the row stride");
+    }
+    std::vector<int32_t> st(games.size(), 0);
+    const int rc = set_roots_impl(e, static_cast<int>(games.size()), games.data(), ids.data(), ns.data(), st.data());
+    if (status)
+        for (size_t k = 0; k < games.size(); ++k) status[games[k]] = st[k];
+    return rc;
 }
 
 int ao_get_moves(ao_engine* e, int g, int32_t* out, int32_t* n) {

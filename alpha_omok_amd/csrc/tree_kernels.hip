@@ -291,15 +291,22 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// k_walk: move the root of ONE game along `extra` moves (ZeroAgent.get_pi with an arbitrary id
-// that extends the previous root id). status: 0 fresh, 1 known but unexpanded, 2 expanded.
+// k_walk: move the roots of the listed games along their `extra` moves (ZeroAgent.get_pi with an
+// arbitrary id that extends the previous root id). One workgroup per listed game: entry b walks game
+// games[b] along extra[b * stride .. + m[b]). status: 0 fresh, 1 known but unexpanded, 2 expanded,
+// -1 illegal move in the id.
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
-__global__ __launch_bounds__(64) void k_walk(TreeParams p, int g, const int32_t* extra, int m,
-                                             int prev_known, int32_t* status_out) {
+__global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games, const int32_t* extra_all, int stride,
+                                             const int32_t* m_all, const int32_t* prev_known_all, int32_t* status_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     int32_t* s_old = reinterpret_cast<int32_t*>(s_dyn);
     const int lane = lane_id();
+    const int b = blockIdx.x;
+    const int g = games[b];
+    const int32_t* extra = extra_all + static_cast<size_t>(b) * stride;
+    const int m = m_all[b];
+    const int prev_known = prev_known_all[b];
     int node = p.root_node[g];
     Pos rp = p.rootpos[g];
     // `known`: the current id is a key of the reference's dict
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, int g, const int32_t*
     if (lane == 0) {
         rp.nchild = 0;
         p.rootpos[g] = rp;
-        *status_out = bad ? -1 : status;
+        status_out[b] = bad ? -1 : status;
     }
 }
 
@@ -395,10 +402,10 @@ void launch_play(const TreeParams& p, hipStream_t s) {
     const size_t lds = 2496 + 2048 + static_cast<size_t>(p.cap) * 4;
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_play<NCH>, dim3(p.G), dim3(64), lds, s, p));
 }
-void launch_walk(const TreeParams& p, int g, const int32_t* extra, int m, int prev_known,
-                 int32_t* status_out, hipStream_t s) {
+void launch_walk(const TreeParams& p, int count, const int32_t* games, const int32_t* extra, int stride, const int32_t* m,
+                 const int32_t* prev_known, int32_t* status_out, hipStream_t s) {
     const size_t lds = static_cast<size_t>(p.cap) * 4 + 16;
-    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_walk<NCH>, dim3(1), dim3(64), lds, s, p, g, extra, m,
+    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_walk<NCH>, dim3(count), dim3(64), lds, s, p, games, extra, stride, m,
                                                    prev_known, status_out));
 }
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s) {

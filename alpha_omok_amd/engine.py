@@ -147,6 +147,23 @@ class Engine:
         self._check(self._L.ao_set_root(self._h, game, _ptr(mv, C.c_int32), mv.size, C.byref(st)), "ao_set_root")
         return st.value
 
+    def set_roots(self, ids, mask=None):
+        """ids: one reference-style root id (0, a1, a2, ...) per game; mask selects the games that move. One
+        launch for all of them. Returns the AO_ROOT_* status per game (int32 [G], -2 where unmasked)."""
+        mv = np.zeros((self.G, self.A), np.int32)
+        n = np.zeros(self.G, np.int32)
+        for g, rid in enumerate(ids):
+            if mask is not None and not mask[g]:
+                continue
+            m = list(rid)[1:]
+            n[g] = len(m)
+            mv[g, :len(m)] = m
+        st = np.full(self.G, -2, np.int32)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self._check(self._L.ao_set_roots(self._h, _ptr(mk, C.c_uint8), _ptr(mv, C.c_int32), self.A, _ptr(n, C.c_int32),
+                                         _ptr(st, C.c_int32)), "ao_set_roots")
+        return st
+
     def get_moves(self, game):
         mv = np.zeros(self.A + 1, np.int32)
         n = C.c_int32(0)

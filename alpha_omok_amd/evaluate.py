@@ -4,6 +4,14 @@ eval_main.py:137-170,191-198,229-333 without pygame / Flask).
 Each player keeps its own tree; after the opponent's reply the next `get_pi(root_id)` re-roots two
 plies down (known child, possibly unexpanded, or a fresh root when the reply was never reached),
 exactly the call pattern of `Evaluator.get_action`. Players search with noise off and tau = 0.
+
+`evaluate` plays the matches one after another through two drop-in agents, drawing every tie-break
+from the process-global numpy stream like the reference. `evaluate_batched` plays all N_MATCH games
+of eval_main.py:204-333 CONCURRENTLY on two G = n_match engines (one per network): per ply one
+`ao_set_roots` launch moves every match's root in both trees and one fused search per side decides
+the moves of the matches where that side is to move. Concurrent matches cannot share one stream, so
+match i owns a stream seeded seed + i that both of its players draw from in turn -- match i is then
+exactly `np.random.seed(seed + i); play_match(...)`.
 """
 import numpy as np
 
@@ -43,13 +51,15 @@ def play_match(player, enemy, board_size, enemy_turn, max_plies=None):
     return win_index, moves
 
 
-def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo=1500.0):
+def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo=1500.0, return_games=False):
     """n_match games with the colours swapped every game (eval_main.py:213-333). Returns the result
-    tally and the final ELO pair."""
+    tally and the final ELO pair (and the [(win_index, moves)] list with return_games)."""
     result = {'Player': 0, 'Enemy': 0, 'Draw': 0}
     enemy_turn = 1
+    games = []
     for _ in range(n_match):
-        win_index, _ = play_match(player, enemy, board_size, enemy_turn)
+        win_index, moves = play_match(player, enemy, board_size, enemy_turn)
+        games.append((win_index, moves))
         if win_index == 3:
             result['Draw'] += 1
             pw = ew = 0.5
@@ -61,4 +71,72 @@ def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo
             pw, ew = 0.0, 1.0
         player_elo, enemy_elo = elo(player_elo, enemy_elo, pw, ew)
         enemy_turn ^= 1
+    if return_games:
+        return result, (player_elo, enemy_elo), games
     return result, (player_elo, enemy_elo)
+
+
+def evaluate_batched(player_model, enemy_model, board_size, n_mcts_player, n_mcts_enemy=None, inplanes=5, n_match=12,
+                     player_elo=1500.0, enemy_elo=1500.0, seed=0, device=0, max_plies=None):
+    """All n_match games at once (colours swapped every game, eval_main.py:213-333). `*_model`: whatever
+    ZeroAgent.model accepts (a PVNet-shaped module runs on the native forward). Returns (result tally,
+    (player_elo, enemy_elo), [(win_index, moves) per match]); the ELO updates are applied in match order."""
+    from .engine import Engine
+    from .evaluator import Evaluator
+    n_mcts_enemy = n_mcts_player if n_mcts_enemy is None else n_mcts_enemy
+    G = n_match
+    win_mark = 3 if board_size == 3 else 5
+    sides = []
+    for model, sims in ((player_model, n_mcts_player), (enemy_model, n_mcts_enemy)):
+        eng = Engine(board_size, sims, inplanes, games=G, noise=False, device=device)
+        sides.append((eng, Evaluator(device), model))
+    enemy_turn = np.array([1 - (i % 2) for i in range(G)])          # match 0: the player is black
+    ids = [(0,) for _ in range(G)]
+    wins = np.zeros(G, np.int64)
+    running = np.ones(G, bool)
+    # one stream per match, handed from the side that just searched to the side that searches next
+    holder = np.where(enemy_turn == 0, 1, 0)                        # the side that moves first holds the stream
+    for i in range(G):
+        sides[holder[i]][0].seed(i, (seed + i) & 0xFFFFFFFF)
+    tau0 = np.zeros(G, np.int8)
+    ply = 0
+    while running.any():
+        turn = ply % 2
+        for side in (0, 1):                                          # 0 player, 1 enemy
+            mask = running & ((enemy_turn == turn) == (side == 1))
+            if not mask.any():
+                continue
+            eng, ev, model = sides[side]
+            for i in np.nonzero(mask)[0]:
+                if holder[i] != side:                                # the opponent drew last: take the stream over
+                    mt, pos, hg, gs = sides[holder[i]][0].get_rng_state(int(i))
+                    eng.set_rng_state(int(i), mt, pos, hg, gs)
+                    holder[i] = side
+            m8 = mask.astype(np.uint8)
+            eng.set_roots(ids, m8)
+            pi, _, _ = ev.search(eng, model, tau0, active=m8)
+            for i in np.nonzero(mask)[0]:
+                a = int(np.argmax(pi[i]))                            # argmax_onehot of a one-hot: no draw (utils.py:198-205)
+                ids[i] = ids[i] + (a,)
+                wins[i] = utils.check_win(utils.get_board(ids[i], board_size), win_mark)
+                if wins[i] != 0 or (max_plies and len(ids[i]) - 1 >= max_plies):
+                    running[i] = False
+        ply += 1
+    for eng, _, _ in sides:
+        eng.close()
+    result = {'Player': 0, 'Enemy': 0, 'Draw': 0}
+    games = []
+    for i in range(G):
+        w = int(wins[i])
+        games.append((w, list(ids[i][1:])))
+        if w == 3 or w == 0:
+            result['Draw'] += 1
+            pw = ew = 0.5
+        elif (w == 1) == (enemy_turn[i] == 1):
+            result['Player'] += 1
+            pw, ew = 1.0, 0.0
+        else:
+            result['Enemy'] += 1
+            pw, ew = 0.0, 1.0
+        player_elo, enemy_elo = elo(player_elo, enemy_elo, pw, ew)
+    return result, (player_elo, enemy_elo), games

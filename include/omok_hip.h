@@ -78,6 +78,12 @@ int ao_reset(ao_engine *e, const uint8_t *host_mask);
  * the node exists (tree reuse); otherwise the game starts a fresh tree. The engine keeps the
  * subtree of the last root only (what main.self_play / eval_main.del_parents ever revisit). */
 int ao_set_root(ao_engine *e, int game, const int32_t *host_moves, int32_t n, int32_t *status);
+/* The same for every game with mask[g] != 0 (NULL = all) in ONE launch: moves[g * stride .. + n[g]) is game g's
+ * root_id[1:]; status[g] receives AO_ROOT_* (entries of unmasked games are left alone). This is the call pattern of
+ * eval_main.Evaluator.get_action (eval_main.py:137-151, 243-252) for G concurrent matches: after the opponent's
+ * reply every match's id has grown by two plies that this engine did not choose. */
+int ao_set_roots(ao_engine *e, const uint8_t *host_mask, const int32_t *host_moves, int32_t stride,
+                 const int32_t *host_n, int32_t *host_status);
 
 /* ---- one move decision, stepwise (external evaluator) ---- replaces _init_mcts/_mcts
  * (agents.py:82-132). Protocol per move:

@@ -171,6 +171,76 @@ def test_head_to_head_two_agents_match_oracle(oracle):
     assert abs(pe - 1516.0) < 1e-9 and abs(ee - 1484.0) < 1e-9
 
 
+def test_evaluate_matches_reference_eval_main(oracle):
+    """evaluate.evaluate (sequential matches through two drop-in ZeroAgents on the process-global stream) against
+    gv13: moves, the mover's visit counts, stream position after every move, winners, result tally and ELO
+    as the reference's eval_main.Evaluator.get_action / GameState.step / elo produced them."""
+    from alpha_omok_amd import agents, evaluate
+    agents.PRINT_MCTS = False
+    g = load_golden("gv13_eval_head_to_head")
+    for ci in range(int(g["ncases"])):
+        B, SP, SE, mp, me, seed, n_match = g["c%d_cfg" % ci].tolist()
+        pa, pb = agents.ZeroAgent(B, SP, 5, noise=False), agents.ZeroAgent(B, SE, 5, noise=False)
+        pa.model, pb.model = StubModel(oracle, mp), StubModel(oracle, me)
+        np.random.seed(seed)
+        log = []
+
+        class Spy:
+            def __init__(self, ag):
+                self.ag = ag
+
+            def get_pi(self, root_id, tau):
+                pi = self.ag.get_pi(root_id, tau)
+                log.append((self.ag.get_visit().copy(), int(np.random.get_state()[2])))
+                return pi
+
+            def reset(self):
+                self.ag.reset()
+
+        result, (pe, ee), games = evaluate.evaluate(Spy(pa), Spy(pb), B, n_match=n_match, return_games=True)
+        k = 0
+        for i, (win, moves) in enumerate(games):
+            want = g["c%d_moves" % ci][i]
+            assert moves == want[want >= 0].tolist(), (ci, i)
+            assert win == int(g["c%d_win" % ci][i])
+            for t in range(len(moves)):
+                np.testing.assert_array_equal(log[k][0], g["c%d_visit" % ci][i][t])
+                assert log[k][1] == int(g["c%d_mt_pos" % ci][i][t])
+                k += 1
+        assert [result[x] for x in ("Player", "Enemy", "Draw")] == g["c%d_result" % ci].tolist()
+        np.testing.assert_allclose([pe, ee], g["c%d_elo" % ci][-1], rtol=0, atol=1e-9)
+
+
+def test_evaluate_batched_equals_sequential_matches(oracle):
+    """All matches of eval_main.py:204-333 concurrently (two G = n_match engines, one ao_set_roots launch per
+    side and ply): match i must be exactly `np.random.seed(seed + i); play_match(...)` with the colours of
+    match i -- moves, winner, and from those the tally and ELO."""
+    import torch
+    from alpha_omok_amd import agents, evaluate
+    from alpha_omok_amd.pvnet import PVNet
+    agents.PRINT_MCTS = False
+    B, n_match, seed = 9, 6, 40
+    for kind in ("stub", "native"):
+        if kind == "stub":
+            mp, me = StubModel(oracle, 1), StubModel(oracle, 0)
+            SP, SE = 30, 24
+        else:
+            torch.manual_seed(5)
+            mp, me = PVNet(1, 5, 32, B).cuda().eval(), PVNet(2, 5, 32, B).cuda().eval()
+            SP, SE = 20, 28
+        res_b, elo_b, games_b = evaluate.evaluate_batched(mp, me, B, SP, SE, n_match=n_match, seed=seed, max_plies=40)
+        pa, pb = agents.ZeroAgent(B, SP, 5, noise=False), agents.ZeroAgent(B, SE, 5, noise=False)
+        pa.model, pb.model = mp, me
+        enemy_turn = 1
+        for i in range(n_match):
+            np.random.seed(seed + i)
+            win, moves = evaluate.play_match(pa, pb, B, enemy_turn, max_plies=40)
+            assert moves == games_b[i][1], (kind, i)
+            assert win == games_b[i][0]
+            enemy_turn ^= 1
+        assert sum(res_b.values()) == n_match
+
+
 def test_run_loop_iterations_save_and_train(tmp_path):
     """main.run = the reference's __main__ loop (main.py:377-414): iteration 0 only plays, later
     iterations play one game and train on it; checkpoints appear when n_iter % save_every == 0 and

@@ -188,3 +188,33 @@ def test_tictactoe_uct_matches_reference(oracle):
         np.testing.assert_array_equal(n, g["c%d_n" % ci], err_msg="case %d" % ci)
         assert rng.pos == pos
         np.testing.assert_array_equal(rng.state_words(), g["c%d_mt" % ci])
+
+
+def test_gv13_head_to_head_matches_reference(oracle):
+    """Two oracle agents driven the way eval_main drives its players (shared stream, noise off, tau 0, the
+    next root id formed from the mover's id + its move) against the reference's Evaluator.get_action /
+    GameState.step / elo outputs."""
+    g = load_golden("gv13_eval_head_to_head")
+    for ci in range(int(g["ncases"])):
+        B, SP, SE, mp, me, seed, n_match = g["c%d_cfg" % ci].tolist()
+        pa = oracle.Agent(B, SP, 5, noise=False, evaluator="stub%d" % mp)
+        pb = oracle.Agent(B, SE, 5, noise=False, evaluator="stub%d" % me)
+        shared = oracle.Rng(seed)
+        enemy_turn = 1
+        for i in range(n_match):
+            want = g["c%d_moves" % ci][i]
+            want = want[want >= 0]
+            root = (0,)
+            for t, mv in enumerate(want):
+                ag = pb if (t % 2) == enemy_turn else pa
+                ag.rng.set_state(shared.state_words(), shared.pos)
+                pi, vis, pol = ag.get_pi(root, 0)
+                shared.set_state(ag.rng.state_words(), ag.rng.pos)
+                assert int(np.argmax(pi)) == int(mv) and pi.sum() == 1.0, (ci, i, t)
+                np.testing.assert_array_equal(vis, g["c%d_visit" % ci][i][t])
+                assert shared.pos == int(g["c%d_mt_pos" % ci][i][t])
+                root = root + (int(mv),)
+            assert oracle.check_win(oracle.get_board(list(root)[1:], B), 5) == int(g["c%d_win" % ci][i])
+            pa.reset()
+            pb.reset()
+            enemy_turn ^= 1

@@ -13,7 +13,8 @@ planes / board / turn, GV4 numpy RNG stream, GV5 tree parity with the exact-arit
 evaluator, GV6 tree parity with the real PVNet (evaluations recorded for replay), GV7 PVNet
 forward, GV8 augment_dataset order, GV9 main.self_play memory order + z, GV10 one train step,
 GV11 rollout agents (PUCTAgent / UCTAgent.get_pi: one-hot, child visits / q, stream position),
-GV12 the 3x3 UCT search of 1_tictactoe_MCTS/mcts_vs.py under Python's `random` (BASELINE configs[0]).
+GV12 the 3x3 UCT search of 1_tictactoe_MCTS/mcts_vs.py under Python's `random` (BASELINE configs[0]),
+GV13 head-to-head matches through the reference's eval_main.Evaluator.get_action / GameState.step / del_parents / elo.
 """
 import os
 import sys
@@ -535,7 +536,85 @@ def gv12():
     save("gv12_tictactoe_uct", **out)
 
 
-ALL = dict(gv12=gv12, gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
+def gv13():
+    """eval_main.Evaluator.get_action call pattern (eval_main.py:137-151, 229-333): two ZeroAgents (noise off,
+    tau 0) alternate on N matches with the colours swapped every match; after each move the loop forms root_id
+    from the MOVER's root_id, steps the reference env, calls the opponent's del_parents and, at the end of a
+    match, Evaluator.reset() and elo(). The reference's own Evaluator / GameState / elo objects are driven by
+    this loop (main() itself cannot run: it loads checkpoints that do not ship)."""
+    import contextlib
+    import io
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import eval_main as ref_eval
+    finally:
+        os.chdir(cwd)
+    out = {}
+    cases = ((9, 36, 30, 1, 0, 21, 3), (9, 50, 24, 0, 1, 5, 2))   # board, S_player, S_enemy, stub_p, stub_e, seed, matches
+    for ci, (B, SP, SE, mp, me, seed, n_match) in enumerate(cases):
+        ev = ref_eval.Evaluator()
+        ev.player = ref_agents.ZeroAgent(B, SP, 5, noise=False)
+        ev.player.model = StubModel(mp)
+        ev.enemy = ref_agents.ZeroAgent(B, SE, 5, noise=False)
+        ev.enemy.model = StubModel(me)
+        np.random.seed(seed)
+        enemy_turn = 1
+        player_elo, enemy_elo = 1500, 1500
+        result = {'Player': 0, 'Enemy': 0, 'Draw': 0}
+        moves_all, visit_all, pos_all, win_all, elo_all = [], [], [], [], []
+        for i in range(n_match):
+            env = ref_eval.game.GameState('text')
+            board = np.zeros([B, B])
+            root_id = (0,)
+            win_index = 0
+            turn = 0
+            moves, visits, poss = [], [], []
+            while win_index == 0:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    action, action_index = ev.get_action(root_id, board, turn, enemy_turn)
+                mover = ev.player if turn != enemy_turn else ev.enemy
+                root_id = mover.root_id + (action_index,)
+                visits.append(mover.get_visit().copy())
+                with contextlib.redirect_stdout(io.StringIO()):
+                    board, check_valid_pos, win_index, turn, _ = env.step(action)
+                    (ev.enemy if turn == enemy_turn else ev.player).del_parents(root_id)
+                moves.append(int(action_index))
+                poss.append(int(np.random.get_state()[2]))
+            if win_index == 3:
+                result['Draw'] += 1
+                player_elo, enemy_elo = ref_eval.elo(player_elo, enemy_elo, 0.5, 0.5)
+            elif turn == enemy_turn:           # the player made the last move (eval_main.py:288-299)
+                result['Player'] += 1
+                player_elo, enemy_elo = ref_eval.elo(player_elo, enemy_elo, 1, 0)
+            else:
+                result['Enemy'] += 1
+                player_elo, enemy_elo = ref_eval.elo(player_elo, enemy_elo, 0, 1)
+            enemy_turn = abs(enemy_turn - 1)
+            ev.reset()
+            mv = np.full(B * B, -1, np.int32)
+            mv[:len(moves)] = moves
+            moves_all.append(mv)
+            vis = np.zeros((B * B, B * B))
+            vis[:len(visits)] = np.stack(visits)
+            visit_all.append(vis)
+            ps = np.full(B * B, -1, np.int64)
+            ps[:len(poss)] = poss
+            pos_all.append(ps)
+            win_all.append(win_index)
+            elo_all.append((player_elo, enemy_elo))
+        out["c%d_cfg" % ci] = np.array([B, SP, SE, mp, me, seed, n_match], np.int32)
+        out["c%d_moves" % ci] = np.stack(moves_all)
+        out["c%d_visit" % ci] = np.stack(visit_all).astype(np.float32)
+        out["c%d_mt_pos" % ci] = np.stack(pos_all)
+        out["c%d_win" % ci] = np.array(win_all, np.int32)
+        out["c%d_elo" % ci] = np.array(elo_all, np.float64)
+        out["c%d_result" % ci] = np.array([result[k] for k in ("Player", "Enemy", "Draw")], np.int32)
+    out["ncases"] = np.array(len(cases))
+    save("gv13_eval_head_to_head", **out)
+
+
+ALL = dict(gv13=gv13, gv12=gv12, gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
            gv10=gv10)
 
 if __name__ == "__main__":
