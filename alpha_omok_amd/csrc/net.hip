@@ -53,6 +53,8 @@ struct ao_net {
     int ws_boards = 0;
     float *act_x = nullptr, *act_t = nullptr, *hbuf = nullptr, *il_in = nullptr;
     float *tmp_p = nullptr, *tmp_v = nullptr;
+    int* d_status = nullptr;                       // bit 0: an activation left the fp16 range in the split-fp16 trunk
+    bool attr_l[16] = {}, attr_done[16] = {}, lds_attr_done[16] = {};  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
     bool timing = false;
     static constexpr int kRing = 512;
@@ -322,7 +324,6 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                 if (best < 0 || cost < best) { best = cost; nchh = c; }
             }
         }
-        static bool attr_l[16][2] = {};
         auto layer = [&](int l) -> int {
             LayerHArgs a;
             a.src = l == 0 ? static_cast<const void*>(in_il) : static_cast<const void*>((l & 1) ? n->act_x : n->act_t);
@@ -331,6 +332,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.wl = n->convh_wl[l];
             a.layer.sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
             a.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+            a.layer.ovf = n->d_status;
             a.res = (l > 0 && !(l & 1)) ? 1 : 0;
             a.nch = nchh;
             const dim3 grid(groups * nchh * nxt), block(512);
@@ -342,12 +344,12 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         constexpr int XT_ = (W <= 9) ? W : 5;                                                                          \
         constexpr int NX_ = (XT_ < W) ? XT_ + 2 : XT_;                                                                 \
         constexpr size_t lds_ = static_cast<size_t>(2) * NX_ * 4 * 2 * 1024;                                           \
-        if (!attr_l[W][0]) {                                                                                           \
+        if (!n->attr_l[W]) {                                                                                           \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, false>),               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, true>),                \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
-            attr_l[W][0] = true;                                                                                       \
+            n->attr_l[W] = true;                                                                                       \
         }                                                                                                              \
         if (l == 0) hipLaunchKernelGGL((k_layer16h<W, XT_, 4, true>), grid, block, lds_, s, a);                       \
         else hipLaunchKernelGGL((k_layer16h<W, XT_, 4, false>), grid, block, lds_, s, a);                             \
@@ -382,18 +384,18 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layers[l].wl = n->convh_wl[l];
             a.layers[l].sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
             a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+            a.layers[l].ovf = n->d_status;
         }
-        static bool attr_done[16] = {};
         const int idx = n->timing ? timer_begin(n, s) : 0;
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
         constexpr size_t heads_ = (static_cast<size_t>(3) * 128 + 16 * 3 * W * W + 8 * 16 * W * W + 8 * 16 * 128) * 4;  \
         constexpr size_t lds_ = (static_cast<size_t>(2) * W * 4 * 2 * 1024 > heads_) ? static_cast<size_t>(2) * W * 4 * 2 * 1024 : heads_; \
-        if (!attr_done[W]) {                                                                                 \
+        if (!n->attr_done[W]) {                                                                                 \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
-            attr_done[W] = true;                                                                             \
+            n->attr_done[W] = true;                                                                           \
         }                                                                                                    \
         hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                         \
     } break;
@@ -449,16 +451,15 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         }
         // heads below (k_head_conv / k_head_fc on the 16-board layout)
     } else if (group == 16) {
-        static bool lds_attr_done[16] = {};
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
         constexpr int XT_ = (W <= 9) ? W : 5;                                                                \
-        if (!lds_attr_done[W]) {                                                                             \
+        if (!n->lds_attr_done[W]) {                                                                             \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16<W, XT_, 1>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
         }                                                                                                    \
-        lds_attr_done[W] = true;                                                                             \
+        n->lds_attr_done[W] = true;                                                                             \
         launch_trunk16<W>(n, in_il, groups, policy, value, s);                                               \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
@@ -623,6 +624,8 @@ int ao_net_finalize(ao_net* n) {
     n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
     n->convh_wh.clear(); n->convh_wl.clear(); n->convh_sc.clear();
     n->ws_boards = 0;
+    if (net_alloc(n, &n->d_status, 4)) return 1;
+    NET_HIP(n, hipMemset(n->d_status, 0, 16));
     const int P = n->planes, A = n->A;
     auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
         const std::vector<float>* w;
@@ -740,6 +743,21 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
         NET_HIP(n, hipMemcpyAsync(dev_policy, n->tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s));
         NET_HIP(n, hipMemcpyAsync(dev_value, n->tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s));
     }
+    return 0;
+}
+
+int ao_net_status(ao_net* n, void* stream, int32_t* flags, int clear) {
+    if (!n->finalized) return n->fail("ao_net_finalize has not been called");
+    NET_HIP(n, hipSetDevice(n->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t f = 0;
+    NET_HIP(n, hipMemcpyAsync(&f, n->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NET_HIP(n, hipStreamSynchronize(s));
+    if (clear && f) {
+        NET_HIP(n, hipMemsetAsync(n->d_status, 0, sizeof(int32_t), s));
+        NET_HIP(n, hipStreamSynchronize(s));
+    }
+    if (flags) *flags = f;
     return 0;
 }
 

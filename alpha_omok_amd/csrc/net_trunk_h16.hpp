@@ -11,6 +11,7 @@ struct TrunkHLayer {
     const uint4* wl;   // low halves
     const float4* sc;  // BatchNorm scale x 2^-s (s = the layer's weight pre-scale)
     const float4* sh;
+    int* ovf;          // status word of the network: bit 0 is set when an activation left the fp16 range (ao_net_status)
 };
 
 struct TrunkHArgs {
@@ -126,6 +127,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
         }
         return h;
     };
+    float peak = 0.f;  // largest pre-clamp activation this lane wrote
     f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -160,10 +162,12 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
                     for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
                 }
                 half4 hh, hl;
+                peak = fmaxf(fmaxf(peak, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
-                    // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN
+                    // BatchNorm-ed residual tower produces) finite instead of turning the board into inf / NaN; the
+                    // event is reported through L.ovf (ao_net_status), the result of such a forward is not fp32-equivalent
                     const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
                     hh[r] = static_cast<_Float16>(v);
                     hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
@@ -281,6 +285,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     }
     AO_T(t_c);
     epilogue(BW - 1);
+    if (peak > 65504.f) atomicOr(L.ovf, 1);
     // layer boundary inside the workgroup (see k_trunk16)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -366,6 +371,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             }
         }
     };
+    float peak = 0.f;
     f32x4 acc[3][XT];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -394,6 +400,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
                 for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[i][r]) + static_cast<float>(rl[i][r]);
             }
             half4 hh, hl;
+            peak = fmaxf(fmaxf(peak, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
@@ -459,6 +466,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (ye == BW) epilogue(BW - 1);
+    if (peak > 65504.f) atomicOr(L.ovf, 1);
 }
 
 struct LayerHArgs {

@@ -67,6 +67,13 @@ class Net:
         5 group-resident trunk on split-fp16 MFMAs (fp32-accurate; 128 planes, board <= 9x9)."""
         self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
 
+    def status(self, clear=True, stream=None):
+        """Status word (ao_net_status): bit 0 = an activation left the fp16 range in the split-fp16 trunk since
+        the last clear (those forwards were clamped, not fp32-equivalent). Synchronises `stream`."""
+        f = C.c_int32(0)
+        self._check(self._L.ao_net_status(self._h, stream, C.byref(f), 1 if clear else 0), "ao_net_status")
+        return f.value
+
     def dominant_kernel(self, boards):
         """(name, algorithmic FLOPs per launch) of the kernel conv_timing() measures."""
         buf = C.create_string_buffer(256)

@@ -154,6 +154,13 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
  * over (16-board group x row chunk x column tile) (any board up to 15x15, smaller batches), and is
  * what mode 0 picks on such a net for batches of more than ~3800 cells (47 9x9 boards). */
 int  ao_net_set_mode(ao_net *n, int mode);
+/* Status word of the network, read on `stream` (which is synchronised): AO_NET_FP16_RANGE is set when the
+ * split-fp16 trunk (modes 0 / 5 at 128 planes) met an activation beyond the fp16 range and clamped it to 65504 --
+ * the outputs of such a forward are finite but not the fp32-equivalent evaluation of model.py:76-104. clear != 0
+ * resets the word. ao_search checks it after every move, fails that move and switches the network to the
+ * fp32-MFMA trunk (mode 2). */
+enum { AO_NET_FP16_RANGE = 1 };
+int  ao_net_status(ao_net *n, void *stream, int32_t *flags, int clear);
 /* total device time (ms) and launch count of the dominant trunk kernel since the last call
  * (HIP events on the launch stream); used by bench.py's roofline. */
 int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launches);

@@ -235,3 +235,45 @@ def test_resident_trunk_stress_alternating_inputs(mode, rounds):
     torch.cuda.synchronize()
     assert bad == 0, "%d of %d forwards differed from the first result of the same input" % (bad, rounds)
     net.close()
+
+
+@pytest.mark.parametrize("batch", [64, 3072])
+def test_split_fp16_trunk_reports_activations_beyond_fp16_range(batch):
+    """The split-fp16 trunk clamps an activation beyond 65504 (it must stay finite) -- and says so: ao_net_status
+    carries AO_NET_FP16_RANGE, the fused search fails that move loudly and switches the network to the fp32-MFMA
+    trunk, whose outputs for the same checkpoint match torch fp32. batch 64: per-layer kernel, 3072: resident."""
+    import torch
+    from alpha_omok_amd.engine import Engine, EngineError, Net
+    from alpha_omok_amd.pvnet import PVNet
+    B = 9
+    sd = pvnet_weights.make_state_dict(2, 5, 128, B, 4)
+    net = Net(2, 5, 128, B, 0)
+    net.load_state_dict(sd)
+    net.set_mode(5)
+    x = torch.from_numpy((np.random.RandomState(1).rand(batch, 5, B, B) < 0.4).astype(np.float32)).cuda()
+    net(x)
+    assert net.status() == 0                              # an ordinary checkpoint stays in range
+    big = dict(sd)
+    big["bn1.weight"] = (sd["bn1.weight"] * 3.0e5).astype(np.float32)   # conv1 output ~1e5: beyond fp16
+    net.load_state_dict(big)
+    p, v = net(x)
+    assert np.isfinite(p.cpu().numpy()).all() and np.isfinite(v.cpu().numpy()).all()
+    assert net.status(clear=False) == 1 and net.status() == 1 and net.status() == 0
+    if batch != 64:
+        return
+    # the engine refuses the move and falls back to the fp32-MFMA trunk for the next ones
+    net.set_mode(0)
+    eng = Engine(B, 6, 5, games=batch, noise=False)
+    with pytest.raises(EngineError, match="fp16 range"):
+        eng.search(net)
+    eng.reset()
+    pi, vis, pol = eng.search(net)                        # mode 2 now
+    assert np.all(vis.sum(axis=1) == 7) and net.status() == 0
+    ref = PVNet(2, 5, 128, B)
+    ref.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in big.items()})
+    ref.eval()
+    with torch.no_grad():
+        rp, rv = ref(x.cpu())
+    p2, v2 = net(x)
+    assert np.abs(p2.cpu().numpy() - rp.numpy()).max() < TOL and np.abs(v2.cpu().numpy() - rv.numpy()).max() < TOL
+    eng.close()
