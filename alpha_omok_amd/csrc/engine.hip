@@ -149,6 +149,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     ao::TreeParams& p = e->tp;
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
+    p.keep_max = c.node_cap - c.sims - 1;
     p.nchq = (((c.inplanes + 3) / 4) + 7) & ~7;  // worst case of the network's input layouts (net_plan)
     p.nchq_live = p.nchq;
     p.il_group = ao::kGroup;
@@ -166,7 +167,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &p.rstatus, G) || dev_alloc(e, &p.leaf_status, G) || dev_alloc(e, &p.path_len, G) ||
         dev_alloc(e, &p.path_node, static_cast<size_t>(G) * p.maxd) ||
         dev_alloc(e, &p.path_edge, static_cast<size_t>(G) * p.maxd) || dev_alloc(e, &p.leaf_pos, G) ||
-        dev_alloc(e, &p.err, G) || dev_alloc(e, &p.stats, static_cast<size_t>(G) * 4) ||
+        dev_alloc(e, &p.err, G) || dev_alloc(e, &p.trimmed, static_cast<size_t>(G) * 2) || dev_alloc(e, &p.stats, static_cast<size_t>(G) * 4) ||
         dev_alloc(e, &p.out_pi, static_cast<size_t>(G) * A) || dev_alloc(e, &p.out_visit, static_cast<size_t>(G) * A) ||
         dev_alloc(e, &p.out_policy, static_cast<size_t>(G) * A) || dev_alloc(e, &p.action, G) ||
         dev_alloc(e, &p.win, G) || dev_alloc(e, &e->d_active, G) || dev_alloc(e, &e->d_tau, G) ||
@@ -212,6 +213,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     AO_HIP(e, hipMemcpyAsync(p.mt, e->h_mt, sizeof(uint32_t) * 624 * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(p.mtpos, e->h_pos, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned) * 4 * G, e->stream));
+    AO_HIP(e, hipMemsetAsync(p.trimmed, 0, sizeof(int32_t) * 2 * G, e->stream));
     AO_HIP(e, hipMemsetAsync(p.noise_buf, 0, sizeof(double) * G * Ap, e->stream));
     ao::launch_reset(p, nullptr, e->stream);
     AO_HIP(e, hipStreamSynchronize(e->stream));
@@ -496,6 +498,11 @@ static int check_game_errors(ao_engine* e) {
         if (herr[g] & ao::ERR_NODE_CAP) m += " tree arena full (raise ao_config.node_cap)";
         if (herr[g] & ao::ERR_PATH) m += " no selectable child (priors are NaN: the policy summed to 0 over the legal moves -- the reference's prior /= prior.sum(), agents.py:189 -- or the tree is inconsistent)";
         if (herr[g] & ao::ERR_BAD_MOVE) m += " move onto an occupied cell";
+        // leave the engine usable: the error words are cleared and no move is in flight (the caller resets the game)
+        (void)hipMemsetAsync(e->tp.err, 0, sizeof(int32_t) * e->G, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        e->in_move = false;
+        e->ended = false;
         return e->fail(m);
     }
     return 0;
@@ -661,6 +668,18 @@ int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries)
         for (const ao::Pos& m : metas) t += m.nchild;
         *dict_entries = t;
     }
+    return 0;
+}
+
+int ao_trim_stats(ao_engine* e, int64_t* subtrees_dropped, int64_t* reroots_trimmed) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    std::vector<int32_t> per(static_cast<size_t>(e->G) * 2);
+    AO_HIP(e, hipMemcpyAsync(per.data(), e->tp.trimmed, sizeof(int32_t) * per.size(), hipMemcpyDeviceToHost, e->stream));
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    int64_t a = 0, b = 0;
+    for (int g = 0; g < e->G; ++g) { a += per[2 * static_cast<size_t>(g)]; b += per[2 * static_cast<size_t>(g) + 1]; }
+    if (subtrees_dropped) *subtrees_dropped = a;
+    if (reroots_trimmed) *reroots_trimmed = b;
     return 0;
 }
 

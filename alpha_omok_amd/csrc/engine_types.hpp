@@ -49,6 +49,7 @@ enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
 //   ACT uint8  action index of the edge
 struct TreeParams {
     int B, A, Ap, C, win_mark, G, cap, maxd, noise;
+    int keep_max;  // most nodes a re-rooting keeps: cap - sims - 1, so the next move's expansions always fit
     int nchq;  // channel quads of the interleaved input batch: ceil(C/4) rounded up to even
     int nchq_live;  // quads the plane encoder writes: nchq, or ceil(C/4) when the padding quads are known to be zero
     double c_puct;
@@ -68,6 +69,7 @@ struct TreeParams {
     // per simulation scratch
     int32_t* leaf_status; int32_t* path_len; int32_t* path_node; int16_t* path_edge; Pos* leaf_pos;
     int32_t* err;
+    int32_t* trimmed;     // [G][2] cumulative: child subtrees dropped at re-rooting because the arena was full, re-rootings that dropped any
     unsigned* stats;      // [G][4] per game: levels, ties, terminal leaves, evaluated leaves
     const double* sqrt_lut; int sqrt_lut_n;
     // evaluation batch

@@ -182,6 +182,7 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
     if (lane == 0) s_old[0] = old_node;
     __syncthreads();
     int tail = 1;
+    int dropped = 0;
     for (int head = 0; head < tail; ++head) {
         const int o = s_old[head];
         const size_t so = node_slot(p, oa, g, o);
@@ -196,16 +197,23 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
             const bool ex = valid && ch >= 0;
             const uint64_t mk = __ballot(ex);
             const int idx = tail + __popcll(mk & lanes_below());
-            if (ex) s_old[idx] = ch;
+            // A full arena (a long game whose visits keep following the played line): the breadth-first copy stops at
+            // keep_max nodes, so the next move's expansions always fit. A child subtree that is not kept becomes an
+            // unvisited child again (its statistics are forgotten); the event is counted in p.trimmed (ao_trim_stats).
+            const bool keep = ex && idx < p.keep_max;
+            const bool drop = ex && !keep;
+            if (keep) s_old[idx] = ch;
             if (valid) {
-                p.CH[sn * p.Ap + e] = ex ? idx : ch;
-                p.N[sn * p.Ap + e] = p.N[so * p.Ap + e];
-                p.W[sn * p.Ap + e] = p.W[so * p.Ap + e];
-                p.Q[sn * p.Ap + e] = p.Q[so * p.Ap + e];
+                p.CH[sn * p.Ap + e] = keep ? idx : (drop ? CH_UNVISITED : ch);
+                p.N[sn * p.Ap + e] = drop ? 0 : p.N[so * p.Ap + e];
+                p.W[sn * p.Ap + e] = drop ? 0.f : p.W[so * p.Ap + e];
+                p.Q[sn * p.Ap + e] = drop ? 0.f : p.Q[so * p.Ap + e];
                 p.P[sn * p.Ap + e] = p.P[so * p.Ap + e];
                 p.ACT[sn * p.Ap + e] = p.ACT[so * p.Ap + e];
             }
-            tail += __popcll(mk);
+            const int kept = __popcll(__ballot(keep));
+            dropped += __popcll(mk) - kept;
+            tail += kept;
         }
         if (lane == 0) p.meta[sn] = m;
         __syncthreads();
@@ -214,6 +222,10 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
         p.nodes_used[g] = tail;
         p.cur[g] = na;
         p.root_node[g] = 0;
+        if (dropped > 0) {
+            p.trimmed[2 * g] += dropped;
+            p.trimmed[2 * g + 1] += 1;
+        }
     }
 }
 

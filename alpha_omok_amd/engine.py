@@ -242,6 +242,13 @@ class Engine:
         self._check(self._L.ao_tree_nodes(self._h, game, C.byref(a), C.byref(b)), "ao_tree_nodes")
         return a.value, b.value
 
+    def trim_stats(self):
+        """(child subtrees dropped, re-rootings that dropped any) since the engine was created: non-zero only when
+        a game's kept tree outgrew node_cap - sims - 1 nodes (ao_trim_stats)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._L.ao_trim_stats(self._h, C.byref(a), C.byref(b)), "ao_trim_stats")
+        return a.value, b.value
+
     def search_stats(self):
         v = [C.c_int64(0) for _ in range(4)]
         self._check(self._L.ao_search_stats(self._h, *[C.byref(x) for x in v]), "ao_search_stats")

@@ -65,6 +65,7 @@ device = None
 _engine = None
 _evaluator = None
 _episodes_played = 0
+_trim_seen = [0]
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
@@ -109,6 +110,7 @@ def _get_engine(games):
     if _engine is None or _engine.G != games:
         if _engine is not None:
             _engine.close()
+        _trim_seen[0] = 0
         _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device)
     return _engine
 
@@ -185,6 +187,11 @@ def self_play(n_selfplay, seeds=None):
                 slot_ep[g] = ep
                 moves[ep], pis[ep] = [], []
                 eng.seed(int(g), seed_of(ep))
+    dropped, trimmed = eng.trim_stats()
+    if trimmed > _trim_seen[0]:
+        logging.warning('tree arenas full in {} re-rootings so far ({} child subtrees forgotten): raise node_cap'.format(
+            trimmed, dropped))
+        _trim_seen[0] = trimmed
     if use_global:
         mt, pos, hg, gs = eng.get_rng_state(0)
         np.random.set_state(('MT19937', mt, pos, hg, gs))

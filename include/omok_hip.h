@@ -35,7 +35,7 @@ typedef struct ao_config {
     int32_t inplanes;   /* IN_PLANES = 2*history+1 (main.py:34); 3, 5, 7 or 9                  */
     int32_t games;      /* G concurrent games (1 for a drop-in ZeroAgent)                      */
     int32_t noise;      /* Dirichlet root noise on/off (agents.py:40,49)                       */
-    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = 4*(sims+1)          */
+    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = 4*(sims+1); see ao_trim_stats */
     int32_t device;     /* HIP device ordinal                                                  */
     double  c_puct;     /* 0 = 5 (agents.py:48)                                                */
     double  alpha;      /* 0 = 10/board^2 (agents.py:47)                                       */
@@ -123,6 +123,13 @@ int ao_get_moves(ao_engine *e, int game, int32_t *host_moves /*[A]*/, int32_t *n
 int ao_get_root_children(ao_engine *e, int game, int32_t *host_action, double *host_n,
                          double *host_w, double *host_q, double *host_p, int32_t *count);
 int ao_tree_nodes(ao_engine *e, int game, int64_t *expanded, int64_t *dict_entries);
+/* Arena pressure, cumulative since ao_create. A game's arena holds node_cap expanded nodes; the tree kept across
+ * moves (main.py:171 -> agents.py:84) grows by up to `sims` nodes per move when the visits keep following the played
+ * line. Re-rooting therefore keeps at most node_cap - sims - 1 nodes, breadth first: a child subtree beyond that
+ * becomes an unvisited child again (its n / w / q are forgotten -- the one place the engine departs from the
+ * reference's never-pruned dict, and only in games that hit the limit). subtrees_dropped / reroots_trimmed count the
+ * events; both stay 0 while node_cap is large enough (raise ao_config.node_cap otherwise). */
+int ao_trim_stats(ao_engine *e, int64_t *subtrees_dropped, int64_t *reroots_trimmed);
 /* search-shape counters since the last ao_begin_move, summed over games: PUCT levels traversed,
  * k>1 random tie-breaks, terminal leaves, evaluated leaves */
 int ao_search_stats(ao_engine *e, int64_t *levels, int64_t *ties, int64_t *terminal,

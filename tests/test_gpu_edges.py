@@ -36,18 +36,35 @@ def test_other_history_depths_and_noise_off(oracle, inplanes, board, noise):
     eng.close()
 
 
-def test_node_cap_overflow_fails_loudly(oracle):
-    from alpha_omok_amd.engine import Engine, EngineError
-    eng = Engine(9, 40, 5, games=2, noise=True, node_cap=42)   # room for ONE fresh search only
-    run = HostEvalRunner(eng)
-    ev = lambda g, sim, pl: oracle.stub_eval(pl, 1)
-    run.move(ev)
-    eng.play()
-    with pytest.raises(EngineError, match="node_cap"):
-        for _ in range(6):
-            run.move(ev)
-            eng.play()
-    eng.close()
+def test_full_arena_degrades_one_game_at_a_time(oracle):
+    """A kept tree that outgrows the arena no longer aborts the batch (round-1 behaviour: ERR_NODE_CAP failed all G
+    games): re-rooting keeps node_cap - sims - 1 nodes breadth first and forgets the rest, per game, and counts it.
+    With room for ONE search only (node_cap = sims + 2) every re-rooting keeps just the new root; with a large
+    arena nothing is dropped and the same games are the oracle's (checked everywhere else)."""
+    from alpha_omok_amd.engine import Engine
+    S, G = 40, 3
+    ev = lambda g, sim, pl: oracle.stub_eval(pl, 1)   # noqa: E731
+    tight = Engine(9, S, 5, games=G, noise=True, node_cap=S + 2)
+    roomy = Engine(9, S, 5, games=G, noise=True)
+    for e in (tight, roomy):
+        e.seed_all([3, 4, 5])
+    rt, rr = HostEvalRunner(tight), HostEvalRunner(roomy)
+    for t in range(6):
+        pt, vt, _ = rt.move(ev)
+        pr, vr, _ = rr.move(ev)
+        if t == 0:
+            np.testing.assert_array_equal(vt, vr)          # the first search never re-rooted
+        assert (vt.sum(axis=1) >= S).all() and (vt.sum(axis=1) <= S + 1).all()   # nothing inherited: the subtree was dropped
+        assert (vr.sum(axis=1) >= S).all()
+        for g in range(G):
+            assert tight.tree_nodes(g)[0] <= S + 2
+        tight.play()
+        roomy.play()
+    dropped, trimmed = tight.trim_stats()
+    assert trimmed > 0 and dropped >= trimmed
+    assert roomy.trim_stats() == (0, 0)
+    tight.close()
+    roomy.close()
 
 
 def test_illegal_root_id_is_rejected():
