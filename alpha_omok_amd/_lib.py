@@ -61,6 +61,7 @@ SYMBOLS = {
     "ao_get_moves": (C.c_int, [_vp, C.c_int, _i32p, _i32p]),
     "ao_get_root_children": (C.c_int, [_vp, C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _i32p]),
     "ao_tree_nodes": (C.c_int, [_vp, C.c_int, _i64p, _i64p]),
+    "ao_tree_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_trim_stats": (C.c_int, [_vp, _i64p, _i64p]),
     "ao_search_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "ao_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(_vp)]),

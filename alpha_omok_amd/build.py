@@ -19,6 +19,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", INC]
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources and headers: ties a rocprofv3 counter summary under
+    profiles/ to the code it was collected from (bench.py reports `traffic` only when it matches)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + [x for x in HEADERS if not os.path.isabs(x)]):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -65,6 +65,13 @@ struct ao_engine {
     int32_t* h_i32 = nullptr;        // pinned [4][G]
     int sims_left = 0;
     bool in_move = false, ended = false;
+    // HIP-event timing of the per-simulation tree kernel (k_expand_select) on the launch stream
+    bool timing = false;
+    static constexpr int kRing = 256;
+    std::vector<hipEvent_t> ev0, ev1;
+    int ring_head = 0, ring_count = 0;
+    double ms_total = 0.0;
+    int64_t launches = 0;
 
     int fail(const std::string& m) { err = m; return 1; }
 };
@@ -86,6 +93,19 @@ static int dev_alloc(ao_engine* e, T** out, size_t count) {
     e->allocs.push_back(p);
     *out = static_cast<T*>(p);
     return 0;
+}
+
+static void tree_harvest(ao_engine* e, int count) {
+    for (int i = 0; i < count; ++i) {
+        const int idx = (e->ring_head - e->ring_count + ao_engine::kRing * 2) % ao_engine::kRing;
+        (void)hipEventSynchronize(e->ev1[idx]);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->ev0[idx], e->ev1[idx]) == hipSuccess) {
+            e->ms_total += ms;
+            e->launches += 1;
+        }
+        --e->ring_count;
+    }
 }
 
 extern "C" {
@@ -118,6 +138,8 @@ void ao_destroy(ao_engine* e) {
     if (e->h_noise) hipHostFree(e->h_noise);
     if (e->h_out) hipHostFree(e->h_out);
     if (e->h_i32) hipHostFree(e->h_i32);
+    for (auto ev : e->ev0) (void)hipEventDestroy(ev);
+    for (auto ev : e->ev1) (void)hipEventDestroy(ev);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -590,7 +612,16 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     auto one_sim = [&]() -> int {
         if (ao::net_forward_il(net, p.batch_il, e->G, e->d_policy, e->d_value, e->stream))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
+        if (e->timing) {
+            if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);
+            (void)hipEventRecord(e->ev0[e->ring_head], e->stream);
+        }
         ao::launch_expand_select(p, e->stream);
+        if (e->timing) {
+            (void)hipEventRecord(e->ev1[e->ring_head], e->stream);
+            e->ring_head = (e->ring_head + 1) % ao_engine::kRing;
+            ++e->ring_count;
+        }
         AO_HIP(e, hipGetLastError());
         return 0;
     };
@@ -668,6 +699,25 @@ int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries)
         for (const ao::Pos& m : metas) t += m.nchild;
         *dict_entries = t;
     }
+    return 0;
+}
+
+int ao_tree_timing(ao_engine* e, int enable, double* ms_total, int64_t* launches) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    if (e->ev0.empty() && enable) {
+        e->ev0.resize(ao_engine::kRing);
+        e->ev1.resize(ao_engine::kRing);
+        for (int i = 0; i < ao_engine::kRing; ++i) {
+            AO_HIP(e, hipEventCreate(&e->ev0[i]));
+            AO_HIP(e, hipEventCreate(&e->ev1[i]));
+        }
+    }
+    tree_harvest(e, e->ring_count);
+    if (ms_total) *ms_total = e->ms_total;
+    if (launches) *launches = e->launches;
+    e->ms_total = 0.0;
+    e->launches = 0;
+    e->timing = enable != 0;
     return 0;
 }
 

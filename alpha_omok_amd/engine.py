@@ -242,6 +242,12 @@ class Engine:
         self._check(self._L.ao_tree_nodes(self._h, game, C.byref(a), C.byref(b)), "ao_tree_nodes")
         return a.value, b.value
 
+    def tree_timing(self, enable=True):
+        """(total ms, launches) of the per-simulation tree kernel (k_expand_select) since the last call."""
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self._L.ao_tree_timing(self._h, 1 if enable else 0, C.byref(ms), C.byref(cnt)), "ao_tree_timing")
+        return ms.value, cnt.value
+
     def trim_stats(self):
         """(child subtrees dropped, re-rootings that dropped any) since the engine was created: non-zero only when
         a game's kept tree outgrew node_cap - sims - 1 nodes (ao_trim_stats)."""

@@ -365,6 +365,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.tree_timing(True)
     net.conv_timing(True)  # reset + enable HIP-event timing of the trunk conv launches
     fence()
     t0 = time.perf_counter()
@@ -373,6 +374,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     conv_ms, conv_launches = net.conv_timing(False)
+    tree_ms, tree_launches = eng.tree_timing(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
@@ -386,18 +388,24 @@ def main():
         kname, f_launch = net.dominant_kernel(G)
         avg_ms = conv_ms / max(conv_launches, 1)
         achieved = f_launch / (avg_ms * 1e-3) / 1e12 if conv_launches else 0.0
-        # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (they cannot
-        # be collected inside this process); use the committed summary when it is for this workload
+        # HBM bytes per launch come from rocprofv3 PMC passes (they cannot be collected inside this process): the
+        # newest committed summary is used when it was collected from THIS kernel source (csrc hash) on this workload
         traffic = None
         traffic_src = None
+        tree_traffic = None
+        from alpha_omok_amd.build import source_hash
+        csrc_sha = source_hash()
         try:
             import glob
             traffic_src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]  # newest round
             with open(traffic_src) as f:
                 tj = json.load(f)
-            if (tj["kernel"].split("<")[0] == kname.split("<")[0] and G == 4096 and B == 9
-                    and args.blocks == 4 and args.planes == 128):
+            same_code = tj.get("csrc_sha16") == csrc_sha
+            same_load = (G == 4096 and B == 9 and args.blocks == 4 and args.planes == 128)
+            if tj["kernel"].split("<")[0] == kname.split("<")[0] and same_load and same_code:
                 traffic = tj["hbm_bytes_per_launch"]
+            if same_load and same_code and tj.get("tree"):
+                tree_traffic = tj["tree"]
         except Exception:
             traffic = None
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
@@ -452,13 +460,35 @@ def main():
                                             / (SUSTAINED_F16_MFMA_TFLOPS if split16 else 156.0),
                 "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)"
-                                % (os.path.relpath(traffic_src, REPO) if traffic_src else "no profile"),
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % (
+                    (os.path.relpath(traffic_src, REPO) + ("" if traffic is not None else
+                                                            ": NOT used, collected from other kernel sources or another workload"))
+                    if traffic_src else "no profile"),
+                "csrc_sha16": csrc_sha,
                 "flop_per_launch": f_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": conv_launches,
                 "conv_time_share": (conv_ms * 1e-3) / dt if dt > 0 else None,
             },
+        }
+        # the tree side of the path (north_star: HBM GB/s of the tree kernels): k_expand_select = expansion + backup of
+        # simulation i and selection + terminal test + plane encoding of simulation i+1 for every game, one launch
+        d_bar = counters["levels"] / sims_total
+        A_ = B * B
+        tree_bytes = G * (A_ * (16.0 * d_bar + 44.0) + 24.0 * (d_bar + 1.0) + 4.0)   # SURVEY.md 8(d), C = 5
+        tree_avg_ms = tree_ms / max(tree_launches, 1)
+        tree_gbs = tree_bytes / (tree_avg_ms * 1e-3) / 1e9 if tree_launches else 0.0
+        out["roofline_tree"] = {
+            "bound": "hbm", "kernel": "k_expand_select (one wavefront per game, %d games per workgroup)" % 4,
+            "achieved": tree_gbs, "peak": 8000.0, "unit": "GB/s", "frac": tree_gbs / 8000.0,
+            "algorithmic_bytes_per_launch": tree_bytes, "bytes_per_sim_per_game": tree_bytes / G,
+            "mean_select_depth": d_bar, "avg_launch_ms": tree_avg_ms, "launches_timed": tree_launches,
+            "time_share": (tree_ms * 1e-3) / dt if dt > 0 else None,
+            "traffic": (tree_traffic or {}).get("hbm_bytes_per_launch"),
+            "traffic_over_algorithmic": ((tree_traffic or {}).get("hbm_bytes_per_launch") / tree_bytes
+                                         if tree_traffic and tree_traffic.get("hbm_bytes_per_launch") else None),
+            "note": "latency-bound, not bandwidth-bound: each game's descent is a chain of dependent row loads "
+                    "(one wave per game), so GB/s stays far below the HBM peak by construction",
         }
         if train_report is not None:
             out["train_step"] = train_report

@@ -123,6 +123,11 @@ int ao_get_moves(ao_engine *e, int game, int32_t *host_moves /*[A]*/, int32_t *n
 int ao_get_root_children(ao_engine *e, int game, int32_t *host_action, double *host_n,
                          double *host_w, double *host_q, double *host_p, int32_t *count);
 int ao_tree_nodes(ao_engine *e, int game, int64_t *expanded, int64_t *dict_entries);
+/* HIP-event timing of the per-simulation tree kernel of ao_search (k_expand_select: expansion + backup of one
+ * simulation, selection + terminal test + plane encoding of the next -- agents.py:134-239 for every game), recorded
+ * on the engine's launch stream. Returns the total and the number of launches since the previous call and
+ * enables / disables the timing (bench.py's roofline_tree). */
+int ao_tree_timing(ao_engine *e, int enable, double *ms_total, int64_t *launches);
 /* Arena pressure, cumulative since ao_create. A game's arena holds node_cap expanded nodes; the tree kept across
  * moves (main.py:171 -> agents.py:84) grows by up to `sims` nodes per move when the visits keep following the played
  * line. Re-rooting therefore keeps at most node_cap - sims - 1 nodes, breadth first: a child subtree beyond that

@@ -85,6 +85,20 @@ if dom:
         tj["mfma_busy_fraction_of_cycles"] = mfma / (1024.0 * gui / 8.0)
         if row and row[1]:
             tj["effective_clock_ghz"] = (gui / 8.0) / row[1]
+    sys.path.insert(0, REPO)
+    from alpha_omok_amd.build import source_hash
+    tj["csrc_sha16"] = source_hash()
+    tree = [k for (k, cn) in vals if "k_expand_select" in k and cn == "FETCH_SIZE"]
+    if tree:
+        tf, tw = vals.get((tree[0], "FETCH_SIZE")), vals.get((tree[0], "WRITE_SIZE"))
+        trow = c.execute("select avg(end-start), count(*) from kernels where name like '%k_expand_select%'").fetchone()
+        if tf is not None and tw is not None:
+            # narrow (4-8 B per lane) scattered accesses: the 2x FETCH_SIZE correction of the guide is calibrated for wide
+            # streaming reads only, so both readings are kept; `hbm_bytes_per_launch` uses the corrected one (upper bound)
+            tj["tree"] = {"kernel": "k_expand_select", "fetch_size_kib": tf, "write_size_kib": tw,
+                          "hbm_bytes_per_launch": (2.0 * tf + tw) * 1024.0,
+                          "hbm_bytes_per_launch_uncorrected_fetch": (tf + tw) * 1024.0,
+                          "avg_launch_ns": trow[0] if trow else None}
     tj["sq_valu_mfma_busy_cycles"] = mfma
     tj["sq_busy_cycles"] = busy
     tj["grbm_gui_active"] = vals.get((k, "GRBM_GUI_ACTIVE"))
