@@ -277,10 +277,10 @@ def test_set_root_semantics(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("B,S,G,blocks", [(9, 400, 4096, 4), (15, 800, 512, 10)])
+@pytest.mark.parametrize("B,S,G,blocks", [(9, 400, 4096, 4), (15, 800, 1024, 10)])
 def test_full_size_properties_and_sampled_oracle_parity(oracle, B, S, G, blocks):
     """BASELINE configs[2] size (9x9, 4096 games x 400 sims, 4-block net, group-resident trunk) and the per-GPU
-    shape of configs[4] (15x15, 800 sims, 10-block net; half its 1024 games to bound the test time):
+    shape of configs[4] (15x15, 800 sims, 10-block net, all 1024 games of one GPU):
     size-independent properties for every game + bit-exact oracle replay of a few sampled games."""
     import torch
     import pvnet_weights
