@@ -8,6 +8,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libomok_hip.so")
+if os.environ.get("AO_LIB_TAG"):   # developer switch: an experiment build made with AO_BUILD_TAG (timing knock-outs)
+    LIB_PATH = os.path.join(HERE, "libomok_hip_%s.so" % os.environ["AO_LIB_TAG"])
 
 AO_ROOT_FRESH, AO_ROOT_UNEXPANDED, AO_ROOT_EXPANDED = 0, 1, 2
 

@@ -38,9 +38,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tag=None, extra_flags=None):
+    """tag / extra_flags: an experiment build (knock-outs, -DAO_PROF ...) into libomok_hip_<tag>.so, loaded with
+    AO_LIB_TAG=<tag>; the product library has no tag."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    tag = tag or os.environ.get("AO_BUILD_TAG")
+    lib = LIB if not tag else os.path.join(HERE, "libomok_hip_%s.so" % tag)
+    objdir = os.path.join(HERE, "build" if not tag else "build_" + tag)
+    extra = (extra_flags if extra_flags is not None else os.environ.get("AO_EXTRA_FLAGS", "")).split()
     os.makedirs(objdir, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -50,7 +55,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get("AO_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -60,10 +65,10 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

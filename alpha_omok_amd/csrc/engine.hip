@@ -637,18 +637,22 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
         --e->sims_left;
     }
     if (rc) return rc;
-    if (ao_end_move(e, tau, pi, visit, policy)) return 1;
     // the split-fp16 trunk clamps activations beyond the fp16 range and reports it: such a move is not the
-    // fp32-equivalent evaluation the engine promises, so it fails loudly instead of returning numbers
+    // fp32-equivalent evaluation the engine promises, so it fails loudly instead of returning numbers (checked before
+    // the per-game errors: clamped evaluations are what makes priors degenerate)
     int32_t nflags = 0;
     if (ao_net_status(net, e->stream, &nflags, 1)) return e->fail(std::string("ao_net_status: ") + ao_net_last_error(net));
     if (nflags & AO_NET_FP16_RANGE) {
         ao_net_set_mode(net, 2);
+        (void)hipMemsetAsync(e->tp.err, 0, sizeof(int32_t) * e->G, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        e->in_move = false;
+        e->ended = false;
         return e->fail("ao_search: an activation left the fp16 range (|x| > 65504) in the split-fp16 trunk during this move, "
                        "so its evaluations were clamped and are not fp32-equivalent; the network has been switched to the "
                        "fp32-MFMA trunk (ao_net_set_mode 2) for all later calls -- reset the affected games and search again");
     }
-    return 0;
+    return ao_end_move(e, tau, pi, visit, policy);
 }
 
 // ---- introspection ---------------------------------------------------------------------------

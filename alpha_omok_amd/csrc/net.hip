@@ -391,7 +391,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
         constexpr size_t heads_ = (static_cast<size_t>(3) * 128 + 16 * 3 * W * W + 8 * 16 * W * W + 8 * 16 * 128) * 4;  \
-        constexpr size_t lds_ = (static_cast<size_t>(2) * W * 4 * 2 * 1024 > heads_) ? static_cast<size_t>(2) * W * 4 * 2 * 1024 : heads_; \
+        constexpr size_t rows_ = static_cast<size_t>(2) * W * 4 * 2 * 1024 + 64;   /* two row buffers + the split-barrier counter */ \
+        constexpr size_t lds_ = (rows_ > heads_) ? rows_ : heads_;                                            \
         if (!n->attr_done[W]) {                                                                                 \
             NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \

@@ -64,12 +64,39 @@ __device__ unsigned long long ao_prof[8 * 12];
 #ifndef AO_KO
 #define AO_KO 0
 #endif
-#if AO_KO != 0 && !defined(AO_PROF)
+#if AO_KO != 0 && !defined(AO_PROF) && !defined(AO_WRONG_RESULTS_OK)
 #error "AO_KO builds compute wrong results on purpose: timing only, build them with -DAO_PROF"
 #endif
+// Split row barrier of the resident kernel (-DAO_SPLIT_BARRIER=1; measured, NOT the default). The eight waves of a group
+// share the two LDS row buffers, so between input rows they must agree that (a) every wave's share of the next row has
+// landed and (b) every wave has finished reading the row whose buffer is refilled next. With the hardware s_barrier after
+// the row epilogue the two waves of a SIMD run their epilogues (no MFMA) at the same time; in the split form a wave
+// ARRIVES (one LDS atomic add on a monotonic counter) as soon as its slabs are done and its staging share has landed, runs
+// its epilogue, and only then WAITS for the other seven, so one wave's epilogue can run beside its partner's MFMAs.
+// Result (profiles/r2c_trunk16h_barrier_ab.txt, same box, 4096 boards): hard barrier 1.603-1.609 ms, split 1.600-1.601,
+// and with NO row synchronisation at all (results wrong) 1.594 ms -- the row barrier costs < 1 %. The launch time is the
+// sum of the MFMA time and the activation traffic's time (each 170 MB pass over the activations costs ~27 us whether
+// or not waves wait for each other): the chip is power-limited, energy adds up, idle cycles are given back as clock.
+#ifndef AO_SPLIT_BARRIER
+#define AO_SPLIT_BARRIER 0
+#endif
+__device__ __forceinline__ void row_arrive(unsigned* cnt, int lane) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void row_wait(unsigned* cnt, unsigned target) {
+    for (;;) {
+        const unsigned v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
 template <int BW, int NC32, int NCI, bool FIRST>
 __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
-                                              int tile, int lane, unsigned long long* prof, const bool flip) {
+                                              int tile, int lane, unsigned long long* prof, const bool flip,
+                                              unsigned* s_cnt, const unsigned rows_before) {
     // flip: this layer walks the board from the LAST row to the first (logical row y = physical row BW-1-y, tap rows
     // mirrored). Layers alternate direction, so a layer starts with the rows the previous one wrote last -- still in
     // L2 / the Infinity Cache -- instead of the ones that left the caches 340 MB of traffic ago.
@@ -268,6 +295,11 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             __builtin_amdgcn_sched_barrier(0);
         }
         AO_T(t_r1);
+#if AO_SPLIT_BARRIER
+        // arrive: this wave's share of the next row has landed (LDS-direct loads count in vmcnt) and its reads of this
+        // row are done
+        row_arrive(s_cnt, lane);
+#endif
         if (yi >= 1 && (AO_KO != 4 || yi == 1)) epilogue(yi - 1);
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
@@ -276,8 +308,14 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
             acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         AO_T(t_r2);
+#if AO_SPLIT_BARRIER
+        // wait: all NT waves arrived for this row (the layer boundary below is a full barrier: no wait after the last row)
+        if (yi + 1 < BW && AO_KO != 9) row_wait(s_cnt, static_cast<unsigned>(NT) * (rows_before + static_cast<unsigned>(yi) + 1u));
+#else
         // next row staged by all waves (LDS-direct loads count in vmcnt), this row's buffer free
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (AO_KO == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         AO_T(t_r3);
         AO_ACC(1, t_r0, t_r1);
         AO_ACC(2, t_r1, t_r2);
@@ -512,9 +550,13 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     uint4* bufB = a.bufB + gfrag * 64;
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long* pp = prof;
+    // arrival counter of the split row barrier: behind the two row buffers (kTrunkHCntOffset), monotonic over the launch
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_x + static_cast<size_t>(2) * BW * NC32 * 2 * 64);
+    if (threadIdx.x == 0) *s_cnt = 0u;   // (published by the first barrier of conv1's prologue)
     // conv1: fp32 planes -> x
     AO_T(t0);
-    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false);
+    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
+                                     s_cnt, 0u);
     AO_T(t1);
 #ifdef AO_PROF
     for (int k = 0; k < 12; ++k) prof[k] = 0;
@@ -523,7 +565,7 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
         trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
-                                             (l & 1) != 0);
+                                             (l & 1) != 0, s_cnt, static_cast<unsigned>(l) * BW);
     }
     AO_T(t2);
     if (AO_KO != 8) trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);

@@ -37,11 +37,27 @@ class Net:
             raise EngineError("%s: %s" % (what, self._L.ao_net_last_error(self._h).decode()))
 
     def load_state_dict(self, state_dict):
-        """state_dict: name -> array-like (numpy or torch tensor), reference key names."""
-        for name, val in state_dict.items():
-            if hasattr(val, "detach"):
-                val = val.detach().cpu().numpy()
-            arr = np.ascontiguousarray(np.asarray(val), dtype=np.float32).reshape(-1)
+        """state_dict: name -> array-like (numpy or torch tensor), reference key names. Device tensors come over in
+        ONE flattened copy (a per-tensor .cpu() costs ~60 synchronous transfers per export)."""
+        items = list(state_dict.items())
+        dev = [(k, v) for k, v in items if hasattr(v, "is_cuda") and v.is_cuda]
+        host = {}
+        if dev:
+            import torch
+            flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in dev]).cpu().numpy()
+            off = 0
+            for k, v in dev:
+                n = v.numel()
+                host[k] = flat[off:off + n]
+                off += n
+        for name, val in items:
+            if name in host:
+                arr = host[name]
+            else:
+                if hasattr(val, "detach"):
+                    val = val.detach().cpu().numpy()
+                arr = np.ascontiguousarray(np.asarray(val), dtype=np.float32).reshape(-1)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
             self._check(self._L.ao_net_set_param(self._h, name.encode(), _ptr(arr, C.c_float), arr.size),
                         "ao_net_set_param(%s)" % name)
         self._check(self._L.ao_net_finalize(self._h), "ao_net_finalize")

@@ -268,7 +268,7 @@ def test_split_fp16_trunk_reports_activations_beyond_fp16_range(batch):
         eng.search(net)
     eng.reset()
     pi, vis, pol = eng.search(net)                        # mode 2 now
-    assert np.all(vis.sum(axis=1) == 7) and net.status() == 0
+    assert np.all(vis.sum(axis=1) == 6) and net.status() == 0   # fresh roots: S + 1 simulations, S child visits
     ref = PVNet(2, 5, 128, B)
     ref.load_state_dict({k: torch.from_numpy(np.asarray(a)) for k, a in big.items()})
     ref.eval()
