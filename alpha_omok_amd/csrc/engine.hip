@@ -33,8 +33,8 @@ void launch_walk(const TreeParams& p, int count, const int32_t* games, const int
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 // net.hip
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
-                   hipStream_t s);
-void net_plan(const ao_net* n, int boards, int* group, int* nchq);
+                   hipStream_t s, int in_kind);
+void net_plan(const ao_net* n, int boards, int* group, int* nchq, int* kind);
 int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why);
 }  // namespace ao
 
@@ -53,6 +53,7 @@ struct ao_engine {
     uint8_t* d_mask = nullptr;
     std::vector<int32_t> h_walk;     // staging of ao_set_root(s): [G][A] moves + games, counts, prev_known, status
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
+    uint8_t* d_planes_u8 = nullptr;                       // bit planes [Gp][u8_row] (input of the split-fp16 kernels)
     size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
     std::vector<std::vector<int32_t>> moves;
@@ -200,6 +201,10 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     if (dev_alloc(e, &il, static_cast<size_t>(Gp) * A * p.nchq * 4) ||
         dev_alloc(e, &e->d_policy, static_cast<size_t>(Gp) * A) || dev_alloc(e, &e->d_value, Gp))
         return 1;
+    p.u8_row = A <= 128 ? 128 : 256;
+    if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row)) return 1;
+    AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
+    p.batch_u8 = nullptr;
     e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
     AO_HIP(e, hipMemsetAsync(il, 0, e->il_bytes, e->stream));
     p.batch_il = il;
@@ -592,11 +597,14 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     std::string why;
     if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
     // the network announces the interleaved input layout it wants for a batch of G boards
-    ao::net_plan(net, e->G, &e->tp.il_group, &e->tp.nchq);
-    // The padding channels of the input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
+    int in_kind = 1;
+    ao::net_plan(net, e->G, &e->tp.il_group, &e->tp.nchq, &in_kind);
+    // The padding channels of the fp32 input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
     // encoder only writes the quads that hold planes (16 B per lane at a 2 KB stride are partial-line writes --
     // rocprof showed 152 MB of HBM writes per launch for a 42 MB batch). A change of layout re-zeroes the buffer.
-    if (e->il_group_zeroed != e->tp.il_group || e->il_nchq_zeroed != e->tp.nchq) {
+    // The split-fp16 kernels take the planes as BITS instead (in_kind 2): one byte per cell, 81 contiguous bytes per
+    // leaf, and the fp32 batch is not written at all.
+    if (in_kind != 2 && (e->il_group_zeroed != e->tp.il_group || e->il_nchq_zeroed != e->tp.nchq)) {
         AO_HIP(e, hipMemsetAsync(e->tp.batch_il, 0, e->il_bytes, e->stream));
         e->il_group_zeroed = e->tp.il_group;
         e->il_nchq_zeroed = e->tp.nchq;
@@ -609,8 +617,14 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     p.policy = e->d_policy;
     p.value = e->d_value;
     p.nchq_live = (e->cfg.inplanes + 3) / 4;
+    const float* net_in = p.batch_il;
+    if (in_kind == 2) {
+        net_in = reinterpret_cast<const float*>(e->d_planes_u8);
+        p.batch_u8 = e->d_planes_u8;
+        p.batch_il = nullptr;
+    }
     auto one_sim = [&]() -> int {
-        if (ao::net_forward_il(net, p.batch_il, e->G, e->d_policy, e->d_value, e->stream))
+        if (ao::net_forward_il(net, net_in, e->G, e->d_policy, e->d_value, e->stream, in_kind))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
         if (e->timing) {
             if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);

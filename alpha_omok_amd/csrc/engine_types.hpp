@@ -76,6 +76,8 @@ struct TreeParams {
     float* batch_il;      // interleaved [grp][cell][cq][il_group][4] (native network input) or null
     int il_group;         // boards per group of batch_il: 32 (layer kernels) or 16 (group-resident trunk)
     float* batch_nchw;    // [G][C][B][B] or null
+    uint8_t* batch_u8;    // bit planes [G][u8_row] (byte per cell, bit q = plane q) or null: the split-fp16 network's input
+    int u8_row;           // 128 (A <= 128) or 256
     const float* policy;  // [G][A]
     const float* value;   // [G]
     // move results

@@ -54,7 +54,8 @@ struct ao_net {
     float *act_x = nullptr, *act_t = nullptr, *hbuf = nullptr, *il_in = nullptr;
     float *tmp_p = nullptr, *tmp_v = nullptr;
     int* d_status = nullptr;                       // bit 0: an activation left the fp16 range in the split-fp16 trunk
-    bool attr_l[16] = {}, attr_done[16] = {}, lds_attr_done[16] = {};  // dynamic-LDS attribute set for this net's device
+    bool attr_l[16][2] = {}, attr_done[16] = {}, lds_attr_done[16] = {};
+    int force_xt = 0, force_nch = 0;               // AO_XT / AO_NCH: tiling overrides for timing experiments (read at create)  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
     bool timing = false;
     static constexpr int kRing = 512;
@@ -167,8 +168,11 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
 
 int pick_mode_public(const ao_net* n, int boards) { return pick_mode(n, boards, nullptr); }
 
-void net_plan(const ao_net* n, int boards, int* group, int* nchq) {
+// kind (may be null): the input the planned kernels take -- 1 the interleaved fp32 plane batch, 2 the engine's bit
+// planes ([boards][kPlaneRow] bytes, bit q = plane q; split-fp16 kernels, C <= 8): what ao_search's encoder writes
+void net_plan(const ao_net* n, int boards, int* group, int* nchq, int* kind) {
     const int mode = pick_mode(n, boards, nullptr);
+    if (kind) *kind = (mode == 5 && n->C <= 8) ? 2 : 1;
     if (mode == 2 || mode == 4 || mode == 5) { *group = 16; *nchq = n->nchq16; }
     else if (mode == 3) { *group = 1; *nchq = n->nchq1; }
     else { *group = 32; *nchq = n->nchq32; }
@@ -251,14 +255,15 @@ static HeadParams head_params(const ao_net* n) {
 
 // in_il: interleaved batch in the layout net_plan(n, boards) announced. policy/value must have
 // room for `boards` rounded up to the plan's group size.
-int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s) {
+int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s, int in_kind) {
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
     int group = 32, nchq = 0, nch = 1;
     bool heads_h16 = false;   // the separate head kernels read the split-fp16 layout
-    net_plan(n, boards, &group, &nchq);
+    net_plan(n, boards, &group, &nchq, nullptr);
     const int mode = pick_mode(n, boards, &nch);
+    if (in_kind == 2 && !(mode == 5 && n->C <= 8)) return n->fail("bit planes handed to a kernel that takes the fp32 batch");
     const int groups = (boards + group - 1) / group;
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
@@ -314,16 +319,32 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
 #endif
         // split-fp16 trunk, one launch per conv: workgroup = (16-board group, row chunk, column tile). For batches
         // that cannot give every CU a whole group, and for boards wider than 9 (a staged row must fit LDS twice)
-        const int nxt = n->B <= 9 ? 1 : (n->B + 4) / 5;
-        int nchh = 1;
+        // Tiling of a wide board: column tiles of XT = 5 or 4 cells (+ a halo column each side) x row chunks. Every
+        // workgroup fills a CU (8 waves x ~250 registers), so the plan is judged by rounds of workgroups over the CUs
+        // x the work of one workgroup: its MFMA cells (rows x XT) plus, weighted, the cells it stages (halo rows and
+        // columns included). 15 x 15 at 64 groups: XT = 4 gives 256 workgroups that each carry all 15 rows of their
+        // tile (one round, no row halos, weights fetched once per group and tile); XT = 5 needs 768 workgroups of 4
+        // rows (three rounds, two extra staged rows each).
+        int xt = n->B, nchh = 1;
         {
-            long best = -1;
-            for (int c = 1; c <= n->B; ++c) {
-                const long rounds = (static_cast<long>(groups) * c * nxt + n->num_cu - 1) / n->num_cu;
-                const long cost = rounds * ((n->B + c - 1) / c + 1);   // rows of a chunk + its halo rows' staging
-                if (best < 0 || cost < best) { best = cost; nchh = c; }
+            double best = -1.0;
+            const int xts[2] = {5, 4};
+            for (int k = 0; k < (n->B <= 9 ? 1 : 2); ++k) {
+                const int x = n->B <= 9 ? n->B : xts[k];
+                const int ntile = (n->B + x - 1) / x;
+                const int staged_cols = n->B <= 9 ? x : x + 2;
+                for (int c = 1; c <= n->B; ++c) {
+                    const long rounds = (static_cast<long>(groups) * c * ntile + n->num_cu - 1) / n->num_cu;
+                    const int rows = (n->B + c - 1) / c;
+                    const int staged_rows = rows + (c > 1 ? 2 : 0);
+                    const double cost = rounds * (static_cast<double>(rows) * x + 0.25 * staged_rows * staged_cols + 2.0);
+                    if (best < 0 || cost < best) { best = cost; nchh = c; xt = x; }
+                }
             }
+            if (n->force_xt > 0 && n->B > 9) xt = n->force_xt;
+            if (n->force_nch > 0) nchh = n->force_nch;
         }
+        const int nxt = (n->B + xt - 1) / xt;
         auto layer = [&](int l) -> int {
             LayerHArgs a;
             a.src = l == 0 ? static_cast<const void*>(in_il) : static_cast<const void*>((l & 1) ? n->act_x : n->act_t);
@@ -338,25 +359,34 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             const dim3 grid(groups * nchh * nxt), block(512);
             const bool timed = n->timing && l > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
+#define AO_LAYERH_LAUNCH(W, XT_)                                                                                       \
+    do {                                                                                                               \
+        constexpr int NX_ = (XT_ < W) ? XT_ + 2 : XT_;                                                                 \
+        constexpr size_t lds_ = static_cast<size_t>(2) * NX_ * 4 * 2 * 1024;                                           \
+        if (!n->attr_l[W][XT_ == 4]) {                                                                                 \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, 0>),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, 1>),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, 2>),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            n->attr_l[W][XT_ == 4] = true;                                                                             \
+        }                                                                                                              \
+        if (l == 0 && in_kind == 2) hipLaunchKernelGGL((k_layer16h<W, XT_, 4, 2>), grid, block, lds_, s, a);          \
+        else if (l == 0) hipLaunchKernelGGL((k_layer16h<W, XT_, 4, 1>), grid, block, lds_, s, a);                     \
+        else hipLaunchKernelGGL((k_layer16h<W, XT_, 4, 0>), grid, block, lds_, s, a);                                 \
+    } while (0)
             switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W: {                                                                                                          \
-        constexpr int XT_ = (W <= 9) ? W : 5;                                                                          \
-        constexpr int NX_ = (XT_ < W) ? XT_ + 2 : XT_;                                                                 \
-        constexpr size_t lds_ = static_cast<size_t>(2) * NX_ * 4 * 2 * 1024;                                           \
-        if (!n->attr_l[W]) {                                                                                           \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, false>),               \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16h<W, XT_, 4, true>),                \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
-            n->attr_l[W] = true;                                                                                       \
-        }                                                                                                              \
-        if (l == 0) hipLaunchKernelGGL((k_layer16h<W, XT_, 4, true>), grid, block, lds_, s, a);                       \
-        else hipLaunchKernelGGL((k_layer16h<W, XT_, 4, false>), grid, block, lds_, s, a);                             \
+        if (W <= 9) AO_LAYERH_LAUNCH(W, (W <= 9 ? W : 5));                                                             \
+        else if (xt == 4) AO_LAYERH_LAUNCH(W, (W <= 9 ? W : 4));                                                       \
+        else AO_LAYERH_LAUNCH(W, (W <= 9 ? W : 5));                                                                    \
     } break;
                 AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
                 AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
+#undef AO_LAYERH_LAUNCH
             }
             if (timed) timer_end(n, idx, s);
             return 0;
@@ -394,11 +424,14 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         constexpr size_t rows_ = static_cast<size_t>(2) * W * 4 * 2 * 1024 + 64;   /* two row buffers + the split-barrier counter */ \
         constexpr size_t lds_ = (rows_ > heads_) ? rows_ : heads_;                                            \
         if (!n->attr_done[W]) {                                                                                 \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),                 \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16hb<W, 4>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
             n->attr_done[W] = true;                                                                           \
         }                                                                                                    \
-        hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                         \
+        if (in_kind == 2) hipLaunchKernelGGL((k_trunk16hb<W, 4>), dim3(groups), dim3(512), lds_, s, a);    \
+        else hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                 \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
 #undef AO_BW_CASE
@@ -530,6 +563,8 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             n->num_cu = prop.multiProcessorCount;
     }
+    if (const char* v = getenv("AO_XT")) n->force_xt = atoi(v) == 4 ? 4 : (atoi(v) == 5 ? 5 : 0);
+    if (const char* v = getenv("AO_NCH")) n->force_nch = atoi(v) > 0 && atoi(v) <= board ? atoi(v) : 0;
     *out = n;
     return 0;
 }
@@ -731,7 +766,7 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ao::ensure_workspace(n, batch)) return 1;
     int group = 32, nchq = 0;
-    ao::net_plan(n, batch, &group, &nchq);
+    ao::net_plan(n, batch, &group, &nchq, nullptr);
     const int boards = (batch + group - 1) / group * group;
     // the heads write rows for the padding boards too: run into scratch unless the batch is whole
     float* pol = (boards == batch) ? dev_policy : n->tmp_p;
@@ -739,7 +774,7 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
     const size_t total = static_cast<size_t>(boards) * n->A;
     hipLaunchKernelGGL(ao::k_nchw_to_il, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
                        dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, nchq, boards, group);
-    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s)) return 1;
+    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s, 1)) return 1;
     if (boards != batch) {
         NET_HIP(n, hipMemcpyAsync(dev_policy, n->tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s));
         NET_HIP(n, hipMemcpyAsync(dev_value, n->tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s));
@@ -783,7 +818,7 @@ int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launche
 
 int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, double* flop_per_launch) {
     int group = 32, nchq = 0;
-    ao::net_plan(n, boards, &group, &nchq);
+    ao::net_plan(n, boards, &group, &nchq, nullptr);
     const int padded = (boards + group - 1) / group * group;
     const double conv = 2.0 * n->A * 9.0 * n->planes * n->planes * padded;   // one planes->planes 3x3 conv
     const double conv1 = 2.0 * n->A * 9.0 * n->C * n->planes * padded;

@@ -15,7 +15,7 @@ struct TrunkHLayer {
 };
 
 struct TrunkHArgs {
-    const float4* in0;  // fp32 plane batch [grp][cell][quad 8][board 16] (conv1 input)
+    const float4* in0;  // conv1 input: fp32 plane batch [grp][cell][quad 8][board 16], or the bit planes [grp][board 16][row] (IN = 2)
     uint4* bufA;  // conv1 output / ResBlock input-output (split-fp16 layout)
     uint4* bufB;
     int nlayers;  // 1 + 2 * n_block, conv1 included
@@ -93,10 +93,17 @@ __device__ __forceinline__ void row_wait(unsigned* cnt, unsigned target) {
     asm volatile("" ::: "memory");
 }
 
-template <int BW, int NC32, int NCI, bool FIRST>
-__device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
-                                              int tile, int lane, unsigned long long* prof, const bool flip,
-                                              unsigned* s_cnt, const unsigned rows_before) {
+// KIND: 0 = a trunk layer (split-fp16 activations in), 1 = conv1 on the fp32 plane batch, 2 = conv1 on the engine's
+// BIT planes: one byte per (board, cell), bit q = plane q ([board 16][kPlaneRow(BW)] bytes per group) -- the planes are
+// 0/1, so 81 bytes per leaf carry what the fp32 batch spends 2.6 KB on (tree_device.hpp encode_planes).
+__host__ __device__ constexpr int kPlaneRow(int bw) { return bw * bw <= 128 ? 128 : 256; }
+template <int BW, int NC32, int NCI, int KIND>
+struct TrunkHLayerFn {
+static __device__ __forceinline__ void run(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
+                                           int tile, int lane, unsigned long long* prof, const bool flip,
+                                           unsigned* s_cnt, const unsigned rows_before) {
+    constexpr bool FIRST = KIND != 0;
+    constexpr bool BITS = KIND == 2;
     // flip: this layer walks the board from the LAST row to the first (logical row y = physical row BW-1-y, tap rows
     // mirrored). Layers alternate direction, so a layer starts with the rows the previous one wrote last -- still in
     // L2 / the Infinity Cache -- instead of the ones that left the caches 340 MB of traffic ago.
@@ -115,7 +122,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_src =
-        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+        make_rsrc(src, BITS ? 16u * kPlaneRow(BW) : FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
     const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
     // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of the
     // SIMD computes meanwhile)
@@ -141,6 +148,15 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     }
     // conv1: one fragment = channels 8*kq .. 8*kq+7 of (cell, board b) = two float4 quads of the fp32 batch
     auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
+        if (BITS) {
+            // channels 0..7 of (cell, board b) = the bits of one byte; only the kq == 0 lanes carry channels < 8
+            const unsigned bits = __builtin_amdgcn_raw_buffer_load_b8(rs_src, b * kPlaneRow(BW) + cell, 0, 0);
+            half8 h;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                h[k] = (kq == 0 && split == 0 && ((bits >> k) & 1u)) ? static_cast<_Float16>(1.0f) : static_cast<_Float16>(0.0f);
+            return h;
+        }
         const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
         const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
         const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
@@ -331,6 +347,7 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
     AO_T(t_d);
     AO_ACC(4, t_c, t_d);
 }
+};
 
 // The same layer for ONE (row chunk [yb, ye), column tile x0 .. x0+XT-1) of a group: the per-layer form for
 // batches too small to give every CU a whole group (k_layer16h: one launch per conv, workgroup = group x row
@@ -338,9 +355,11 @@ __device__ __forceinline__ void trunk_h_layer(const void* src, uint4* dst, const
 // plus one halo column on each side = 7 cells = 56 KB, two of them 112 KB). Halo columns that fall off the
 // board are staged as zeros, so the MFMA stream needs no per-column conditions; halo rows are handled by the
 // slab conditions (uniform per row) exactly as in the fp32 row-chunk kernel.
-template <int BW, int XT, int NC32, int NCI, bool FIRST>
+template <int BW, int XT, int NC32, int NCI, int KIND>
 __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES,
                                                    uint4* s_x, int tile, int lane, int x0, int yb, int ye) {
+    constexpr bool FIRST = KIND != 0;
+    constexpr bool BITS = KIND == 2;
     constexpr int A = BW * BW;
     constexpr bool HALO = XT < BW;
     constexpr int NX = HALO ? XT + 2 : XT;   // staged input cells per row; staged cell j = board column x0 - 1 + j (HALO) or j
@@ -356,7 +375,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
     const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_src =
-        make_rsrc(src, FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
+        make_rsrc(src, BITS ? 16u * kPlaneRow(BW) : FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
     const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
     half8 wA[2][3], wB[2][3], wres[2][FIRST ? 9 : 1];
     auto load_w = [&](int slab, half8 (&W)[2][3]) {
@@ -377,6 +396,15 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
         }
     }
     auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
+        if (BITS) {
+            // channels 0..7 of (cell, board b) = the bits of one byte; only the kq == 0 lanes carry channels < 8
+            const unsigned bits = __builtin_amdgcn_raw_buffer_load_b8(rs_src, b * kPlaneRow(BW) + cell, 0, 0);
+            half8 h;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                h[k] = (kq == 0 && split == 0 && ((bits >> k) & 1u)) ? static_cast<_Float16>(1.0f) : static_cast<_Float16>(0.0f);
+            return h;
+        }
         const int o = ((cell * 8 + 2 * kq) * 16 + b) * 16;
         const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o, 0, 0);
         const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_src, o + 256, 0, 0);
@@ -514,7 +542,7 @@ struct LayerHArgs {
     int res, nch;
 };
 
-template <int BW, int XT, int NC32, bool FIRST>
+template <int BW, int XT, int NC32, int KIND>
 __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
     constexpr int A = BW * BW;
     constexpr int NXT = (BW + XT - 1) / XT;
@@ -528,17 +556,20 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     uint4* dst = a.dst + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
-    if (FIRST) {
-        trunk_h_layer_tile<BW, XT, NC32, 1, true>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
-                                                  false, s_x, tile, lane, xt * XT, yb, ye);
+    if (KIND == 2) {
+        trunk_h_layer_tile<BW, XT, NC32, 1, 2>(static_cast<const uint8_t*>(a.src) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), dst,
+                                               a.layer, false, s_x, tile, lane, xt * XT, yb, ye);
+    } else if (KIND == 1) {
+        trunk_h_layer_tile<BW, XT, NC32, 1, 1>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
+                                               false, s_x, tile, lane, xt * XT, yb, ye);
     } else {
-        trunk_h_layer_tile<BW, XT, NC32, NC32, false>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
+        trunk_h_layer_tile<BW, XT, NC32, NC32, 0>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
                                                       a.layer, a.res != 0, s_x, tile, lane, xt * XT, yb, ye);
     }
 }
 
-template <int BW, int NC32>
-__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
+template <int BW, int NC32, int INK>   // INK: 1 fp32 plane batch, 2 bit planes (see trunk_h_layer)
+__device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     constexpr int A = BW * BW;
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][row fragments][64] uint4
     const int grp = blockIdx.x;
@@ -555,8 +586,12 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     if (threadIdx.x == 0) *s_cnt = 0u;   // (published by the first barrier of conv1's prologue)
     // conv1: fp32 planes -> x
     AO_T(t0);
-    trunk_h_layer<BW, NC32, 1, true>(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
-                                     s_cnt, 0u);
+    if (INK == 2)
+        TrunkHLayerFn<BW, NC32, 1, 2>::run(reinterpret_cast<const uint8_t*>(a.in0) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), bufA,
+                                      a.layers[0], false, s_x, tile, lane, pp, false, s_cnt, 0u);
+    else
+        TrunkHLayerFn<BW, NC32, 1, 1>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
+                                      s_cnt, 0u);
     AO_T(t1);
 #ifdef AO_PROF
     for (int k = 0; k < 12; ++k) prof[k] = 0;
@@ -564,7 +599,7 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     for (int l = 1; l < a.nlayers; ++l) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
-        trunk_h_layer<BW, NC32, NC32, false>(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
+        TrunkHLayerFn<BW, NC32, NC32, 0>::run(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
                                              (l & 1) != 0, s_cnt, static_cast<unsigned>(l) * BW);
     }
     AO_T(t2);
@@ -577,6 +612,16 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
     if (grp == 5 && lane == 0)
         for (int k = 0; k < 12; ++k) ao_prof[tile * 12 + k] = prof[k];
 #endif
+}
+
+// conv1 on the fp32 plane batch (ao_net_forward: any float planes) / on the engine's bit planes (ao_search)
+template <int BW, int NC32>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
+    trunk16h_body<BW, NC32, 1>(a);
+}
+template <int BW, int NC32>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16hb(TrunkHArgs a) {
+    trunk16h_body<BW, NC32, 2>(a);
 }
 
 }  // namespace ao

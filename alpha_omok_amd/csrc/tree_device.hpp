@@ -251,6 +251,11 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
             const unsigned later = recent & ((1u << j) - 1u) & ((j & 1) ? 0xAAu : 0x55u);
             return (own[col] && later == 0u) ? 1.f : 0.f;
         };
+        if (p.batch_u8) {
+            unsigned bits = 0;
+            for (int q = 0; q < C; ++q) bits |= (plane(q) != 0.f) ? (1u << q) : 0u;
+            p.batch_u8[static_cast<size_t>(g) * p.u8_row + cell] = static_cast<uint8_t>(bits);
+        }
         if (p.batch_nchw) {
             for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = plane(q);
         }

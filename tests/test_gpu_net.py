@@ -277,3 +277,45 @@ def test_split_fp16_trunk_reports_activations_beyond_fp16_range(batch):
     p2, v2 = net(x)
     assert np.abs(p2.cpu().numpy() - rp.numpy()).max() < TOL and np.abs(v2.cpu().numpy() - rv.numpy()).max() < TOL
     eng.close()
+
+
+@pytest.mark.parametrize("B,G,S,nb,C", [(9, 64, 24, 2, 5), (9, 3072, 12, 1, 5), (15, 40, 16, 2, 5), (9, 50, 20, 1, 7), (5, 80, 20, 1, 3)])
+def test_fused_search_on_bit_planes_equals_stepwise_on_float_planes(B, G, S, nb, C):
+    """ao_search hands the split-fp16 kernels the leaf planes as BITS (one byte per cell, written by the tree kernel;
+    k_trunk16hb / k_layer16h<.., 2>), the stepwise protocol hands the same network fp32 NCHW planes through
+    ao_net_forward (k_nchw_to_il + the fp32-plane kernels). The planes are 0/1, so conv1 sees identical operands and
+    the two searches must agree bit for bit -- visits, priors, moves -- on the per-layer kernel (G = 64, 15 x 15),
+    the resident kernel (3072 boards = 192 groups) and other history depths (C = 3, 7)."""
+    import torch
+    from alpha_omok_amd.engine import Engine
+    from gpu_helpers import HostEvalRunner
+    net = _native(nb, C, 128, B, 9)
+    net.set_mode(5)
+    seeds = np.arange(40, 40 + G, dtype=np.uint32)
+    e1 = Engine(B, S, C, games=G, noise=True)
+    e2 = Engine(B, S, C, games=G, noise=True)
+    e1.seed_all(seeds)
+    e2.seed_all(seeds)
+    run = HostEvalRunner(e2)
+    for t in range(3):
+        tau = np.full(G, 1 if t < 2 else 0, np.int8)
+        pi1, vis1, pol1 = e1.search(net, tau=tau)
+        e2.begin_move()
+        while e2.sims_left() > 0:
+            e2.collect_leaves(run.planes.data_ptr())
+            e2.sync()
+            p, v = net(run.planes)
+            torch.cuda.synchronize()
+            e2.apply_evals(p.data_ptr(), v.data_ptr())
+        pi2, vis2, pol2 = e2.end_move(tau)
+        np.testing.assert_array_equal(vis1, vis2)
+        np.testing.assert_array_equal(pol1, pol2)
+        np.testing.assert_array_equal(pi1, pi2)
+        a1, w1 = e1.play()
+        a2, w2 = e2.play()
+        np.testing.assert_array_equal(a1, a2)
+        np.testing.assert_array_equal(w1, w2)
+    assert net.status() == 0
+    e1.close()
+    e2.close()
+    net.close()
