@@ -55,22 +55,107 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int r) {
 // ----------------------------------------------------------------------------------------------
 // positions
 // ----------------------------------------------------------------------------------------------
+// Word `w` of a bitboard WITHOUT a dynamically indexed access: `cell >> 6` differs from lane to lane, and a per-lane
+// index into Pos::bb makes the compiler keep the whole 80-byte position in scratch (private memory: 20 dwords x 64
+// lanes = 5 KB of global traffic per copy -- rocprof showed 16 KB written per game and simulation, five times the
+// tree's own rows). The four words are passed BY VALUE and picked by selects: handed a pointer, instcombine folds
+// "select of loads" back into a load through a selected address and the position is pinned in scratch again.
+__device__ __forceinline__ uint64_t pick4(uint64_t a, uint64_t b, uint64_t c, uint64_t d, int w) {
+    uint64_t v = a;
+    v = (w == 1) ? b : v;
+    v = (w == 2) ? c : v;
+    v = (w == 3) ? d : v;
+    return v;
+}
+template <int C, class PT>
+__device__ __forceinline__ uint64_t pos_word(const PT& s, int w) {
+    return pick4(s.bb[C][0], s.bb[C][1], s.bb[C][2], s.bb[C][3], w);
+}
+template <int C, class PT>
+__device__ __forceinline__ bool pos_test(const PT& s, int cell) {   // colour C has a stone on `cell`
+    return (pos_word<C>(s, cell >> 6) >> (cell & 63)) & 1ull;
+}
+
 __device__ __forceinline__ bool bb_test(const uint64_t* bb, int cell) {
     return (bb[cell >> 6] >> (cell & 63)) & 1ull;
 }
 
-__device__ __forceinline__ bool pos_occupied(const Pos& s, int cell) {
-    return ((s.bb[0][cell >> 6] | s.bb[1][cell >> 6]) >> (cell & 63)) & 1ull;
+// A position as the tree kernels hold it in REGISTERS: the same content as Pos (engine_types.hpp, the 80-byte record in
+// HBM), with the move history as one 64-bit word and every member reachable by compile-time indices only, so nothing
+// forces it into scratch. pos_load / pos_store move it with five 16-byte accesses.
+struct PosR {
+    uint64_t bb[2][kBBWords];
+    uint64_t last64;   // byte i = move (ply - i), 0xFF if none
+    int ply;
+    int nchild;
+    uint32_t pad_;
+};
+
+__device__ __forceinline__ PosR pos_load(const Pos* q) {
+    const uint4* q4 = reinterpret_cast<const uint4*>(q);
+    const uint4 a0 = q4[0], a1 = q4[1], a2 = q4[2], a3 = q4[3], a4 = q4[4];
+    PosR r;
+    r.bb[0][0] = a0.x | (static_cast<uint64_t>(a0.y) << 32); r.bb[0][1] = a0.z | (static_cast<uint64_t>(a0.w) << 32);
+    r.bb[0][2] = a1.x | (static_cast<uint64_t>(a1.y) << 32); r.bb[0][3] = a1.z | (static_cast<uint64_t>(a1.w) << 32);
+    r.bb[1][0] = a2.x | (static_cast<uint64_t>(a2.y) << 32); r.bb[1][1] = a2.z | (static_cast<uint64_t>(a2.w) << 32);
+    r.bb[1][2] = a3.x | (static_cast<uint64_t>(a3.y) << 32); r.bb[1][3] = a3.z | (static_cast<uint64_t>(a3.w) << 32);
+    r.ply = static_cast<int>(static_cast<int16_t>(a4.x & 0xFFFFu));
+    r.nchild = static_cast<int>(static_cast<int16_t>(a4.x >> 16));
+    r.last64 = a4.y | (static_cast<uint64_t>(a4.z) << 32);
+    r.pad_ = a4.w;
+    return r;
+}
+
+__device__ __forceinline__ void pos_store(Pos* q, const PosR& r) {
+    uint4* q4 = reinterpret_cast<uint4*>(q);
+    auto lo = [](uint64_t v) { return static_cast<unsigned>(v); };
+    auto hi = [](uint64_t v) { return static_cast<unsigned>(v >> 32); };
+    q4[0] = make_uint4(lo(r.bb[0][0]), hi(r.bb[0][0]), lo(r.bb[0][1]), hi(r.bb[0][1]));
+    q4[1] = make_uint4(lo(r.bb[0][2]), hi(r.bb[0][2]), lo(r.bb[0][3]), hi(r.bb[0][3]));
+    q4[2] = make_uint4(lo(r.bb[1][0]), hi(r.bb[1][0]), lo(r.bb[1][1]), hi(r.bb[1][1]));
+    q4[3] = make_uint4(lo(r.bb[1][2]), hi(r.bb[1][2]), lo(r.bb[1][3]), hi(r.bb[1][3]));
+    q4[4] = make_uint4((static_cast<unsigned>(r.ply) & 0xFFFFu) | (static_cast<unsigned>(r.nchild) << 16), lo(r.last64), hi(r.last64), r.pad_);
+}
+
+template <class PT>
+__device__ __forceinline__ bool pos_occupied(const PT& s, int cell) {
+    return ((pos_word<0>(s, cell >> 6) | pos_word<1>(s, cell >> 6)) >> (cell & 63)) & 1ull;
 }
 
 // env step / get_board: stone colour alternates, black first (utils.py:171-179)
 __device__ __forceinline__ void pos_place(Pos& s, int cell) {
     const int colour = s.ply & 1;
-    s.bb[colour][cell >> 6] |= 1ull << (cell & 63);
+    const int w = cell >> 6;
+    const uint64_t bit = 1ull << (cell & 63);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < kBBWords; ++i) s.bb[c][i] |= (c == colour && i == w) ? bit : 0ull;
 #pragma unroll
     for (int i = kLastMoves - 1; i > 0; --i) s.last[i] = s.last[i - 1];
     s.last[0] = static_cast<uint8_t>(cell);
     s.ply = static_cast<int16_t>(s.ply + 1);
+}
+
+__device__ __forceinline__ void pos_place(PosR& s, int cell) {
+    const int colour = s.ply & 1;
+    const int w = cell >> 6;
+    const uint64_t bit = 1ull << (cell & 63);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < kBBWords; ++i) s.bb[c][i] |= (c == colour && i == w) ? bit : 0ull;
+    s.last64 = (s.last64 << 8) | static_cast<uint64_t>(cell & 0xFF);
+    s.ply += 1;
+}
+
+__device__ __forceinline__ void pos_clear(PosR& s) {
+#pragma unroll
+    for (int i = 0; i < kBBWords; ++i) { s.bb[0][i] = 0; s.bb[1][i] = 0; }
+    s.ply = 0;
+    s.nchild = 0;
+    s.last64 = ~0ull;
+    s.pad_ = 0;
 }
 
 __device__ __forceinline__ void pos_clear(Pos& s) {
@@ -89,7 +174,8 @@ __device__ __forceinline__ void pos_clear(Pos& s) {
 // scan because the parent position was not terminal: only a line through the new stone can be
 // new, and any run >= win_mark contains a window of exactly win_mark (overlines count).
 // `mover` = colour index (0 / 1) of the stone just placed, `stones` = stones on the board now.
-__device__ __forceinline__ int win_after_move_by(const Pos& s, int cell, int B, int win_mark, int mover, int stones) {
+template <class PT>
+__device__ __forceinline__ int win_after_move_by(const PT& s, int cell, int B, int win_mark, int mover, int stones) {
     const int lane = lane_id();
     // lane l < 32: direction l>>3, offset index l&7 -> offsets -4..-1, +1..+4
     const int dir = (lane >> 3) & 3;
@@ -100,7 +186,14 @@ __device__ __forceinline__ int win_after_move_by(const Pos& s, int cell, int B, 
     const int r = cell / B + off * dr;
     const int c = cell % B + off * dc;
     bool bit = false;
-    if (lane < 32 && r >= 0 && r < B && c >= 0 && c < B) bit = bb_test(s.bb[mover], r * B + c);
+    if (lane < 32 && r >= 0 && r < B && c >= 0 && c < B) {
+        const int cl = r * B + c;
+        // (a mask blend, not `mover ? .. : ..`: the compiler turns that into a select of two POINTERS into the position,
+        // which pins it in scratch)
+        const uint64_t mk = 0ull - static_cast<uint64_t>(mover & 1);
+        const uint64_t wd = (pos_word<0>(s, cl >> 6) & ~mk) | (pos_word<1>(s, cl >> 6) & mk);
+        bit = (wd >> (cl & 63)) & 1ull;
+    }
     const uint64_t m = __ballot(bit);
     bool won = false;
 #pragma unroll
@@ -117,7 +210,8 @@ __device__ __forceinline__ int win_after_move_by(const Pos& s, int cell, int B, 
     return 0;
 }
 
-__device__ __forceinline__ int win_after_move(const Pos& s, int cell, int B, int win_mark) {
+template <class PT>
+__device__ __forceinline__ int win_after_move(const PT& s, int cell, int B, int win_mark) {
     return win_after_move_by(s, cell, B, win_mark, (s.ply - 1) & 1, s.ply);
 }
 
@@ -219,21 +313,19 @@ struct MtDev {
 // who made move j as they stood after move j. Written into the evaluation batch.
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
-__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const Pos& s) {
+__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s) {
     const int lane = lane_id();
     const int k = s.ply;
     const int stm = k & 1;           // 0: black to move
     const int C = p.C;
     // the last moves as one 64-bit word: byte i = move (ply - i); extracted with shifts (an indexed
     // byte array would live in scratch memory)
-    uint64_t last64 = 0;
-#pragma unroll
-    for (int i = 0; i < kLastMoves; ++i) last64 |= static_cast<uint64_t>(s.last[i]) << (8 * i);
+    const uint64_t last64 = s.last64;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
         if (cell >= p.A) continue;
-        const bool own[2] = {bb_test(s.bb[0], cell), bb_test(s.bb[1], cell)};
+        const unsigned own2 = (pos_test<0>(s, cell) ? 1u : 0u) | (pos_test<1>(s, cell) ? 2u : 0u);   // bit c: colour c has a stone here
         // bit i set <=> this cell received move (ply - i)
         unsigned recent = 0;
 #pragma unroll
@@ -249,7 +341,7 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
             const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
             // later moves of the same player: history entries j-2, j-4, ..., i.e. bits of `recent` below j with j's parity
             const unsigned later = recent & ((1u << j) - 1u) & ((j & 1) ? 0xAAu : 0x55u);
-            return (own[col] && later == 0u) ? 1.f : 0.f;
+            return (((own2 >> col) & 1u) && later == 0u) ? 1.f : 0.f;
         };
         if (p.batch_u8) {
             unsigned bits = 0;
@@ -294,9 +386,9 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     int depth = 0;
     int status = LS_EXPAND_ROOT;
     unsigned levels = 0, ties = 0;
-    Pos lp;
+    PosR lp;
     if (node < 0) {
-        lp = p.rootpos[g];
+        lp = pos_load(p.rootpos + g);
     } else {
         for (;;) {
             const size_t slot = node_slot(p, arena, g, node);
@@ -304,7 +396,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             // ... then, per level, the node record together with all five edge rows. The rows are Ap
             // wide, so the addresses do not depend on the child count; lanes past it are masked after
             // the loads (CH and ACT of the chosen edge then come from a lane shuffle, not from memory).
-            const Pos m = p.meta[slot];
+            const PosR m = pos_load(p.meta + slot);
             int n[NCH], chv[NCH], acv[NCH];
             float qv[NCH];
             double pv[NCH];
@@ -400,7 +492,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     }
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         lp.nchild = 0;
-        if (lane == 0) p.leaf_pos[g] = lp;
+        if (lane == 0) pos_store(p.leaf_pos + g, lp);
         encode_planes<NCH>(p, g, lp);
     }
     if (lane == 0) {
@@ -437,7 +529,7 @@ __device__ __forceinline__ int set_probe(const int16_t* tab, int mask, int key) 
 }
 
 template <int NCH>
-__device__ int legal_order(const Pos& s, int A, uint8_t* s_ord, int16_t* s_tab /*[2][128]*/) {
+__device__ int legal_order(const PosR& s, int A, uint8_t* s_ord, int16_t* s_tab /*[2][128]*/) {
     const int lane = lane_id();
     int L = 0;
     int maxkey = -1;
@@ -530,7 +622,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
     const int depth = p.path_len[g];
     const int newn = p.nodes_used[g];
     const int done = p.sims_done[g];
-    Pos lp = p.leaf_pos[g];
+    PosR lp = pos_load(p.leaf_pos + g);
     const float v_eval = p.value[g];
     float pol[NCH];
 #pragma unroll
@@ -590,8 +682,8 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
             }
         }
         if (lane == 0) {
-            lp.nchild = static_cast<int16_t>(L);
-            p.meta[slot] = lp;
+            lp.nchild = L;
+            pos_store(p.meta + slot, lp);
             p.nodes_used[g] = newn + 1;
             if (status == LS_EXPAND) p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
             else p.root_node[g] = newn;

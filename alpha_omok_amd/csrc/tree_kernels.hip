@@ -187,7 +187,7 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
         const int o = s_old[head];
         const size_t so = node_slot(p, oa, g, o);
         const size_t sn = node_slot(p, na, g, head);
-        const Pos m = p.meta[so];
+        const PosR m = pos_load(p.meta + so);
         const int L = m.nchild;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -215,7 +215,7 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
             dropped += __popcll(mk) - kept;
             tail += kept;
         }
-        if (lane == 0) p.meta[sn] = m;
+        if (lane == 0) pos_store(p.meta + sn, m);
         __syncthreads();
     }
     if (lane == 0) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
     }
     if (action < 0) action = p.A - 1;  // pi == NaN (no visits): numpy would return A here
     // env.step: place the stone, flip the turn, check_win (env_small.py:154-176,196)
-    Pos rp = p.rootpos[g];
+    PosR rp = pos_load(p.rootpos + g);
     const bool occupied = pos_occupied(rp, action);
     pos_place(rp, action);
     const int w = win_after_move(rp, action, p.B, p.win_mark);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
     }
     if (lane == 0) {
         rp.nchild = 0;
-        p.rootpos[g] = rp;
+        pos_store(p.rootpos + g, rp);
         p.action[g] = action;
         p.win[g] = w;
         // the new root is a record of the reference's dict iff its parent was expanded
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games,
     const int m = m_all[b];
     const int prev_known = prev_known_all[b];
     int node = p.root_node[g];
-    Pos rp = p.rootpos[g];
+    PosR rp = pos_load(p.rootpos + g);
     // `known`: the current id is a key of the reference's dict
     bool known = (node >= 0) || prev_known;
     bool bad = false;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games,
     }
     if (lane == 0) {
         rp.nchild = 0;
-        p.rootpos[g] = rp;
+        pos_store(p.rootpos + g, rp);
         status_out[b] = bad ? -1 : status;
     }
 }
@@ -369,9 +369,9 @@ __global__ void k_reset(TreeParams p, const uint8_t* mask) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.G) return;
     if (mask && !mask[g]) return;
-    Pos e;
+    PosR e;
     pos_clear(e);
-    p.rootpos[g] = e;
+    pos_store(p.rootpos + g, e);
     p.root_node[g] = -1;
     p.nodes_used[g] = 0;
     p.cur[g] = 0;
