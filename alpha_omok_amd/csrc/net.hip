@@ -37,7 +37,12 @@ struct ao_net {
     bool finalized = false;
     std::string err;
     std::map<std::string, std::vector<float>> params;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;                      // workspace (grow-only)
+    // parameter buffers: ao_net_finalize runs again after every training step (weights re-exported), always with
+    // the same sequence of sizes, so the buffers of the previous export are reused in order instead of ~60
+    // hipFree + hipMalloc per export
+    std::vector<std::pair<void*, size_t>> pallocs;
+    size_t pcursor = 0;
     // device parameters
     std::vector<float*> conv_w, conv_sc, conv_sh;  // [1 + 2*nb]; conv_w[0] packed for nchq32
     // split-fp16 trunk (mode 5): per trunk conv after conv1 the high / low weight halves (pre-scaled by a
@@ -86,8 +91,30 @@ static int net_alloc(ao_net* n, T** out, size_t count) {
     return 0;
 }
 
+template <typename T>
+static int param_alloc(ao_net* n, T** out, size_t count) {
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    if (n->pcursor < n->pallocs.size() && n->pallocs[n->pcursor].second == bytes) {
+        *out = static_cast<T*>(n->pallocs[n->pcursor++].first);
+        return 0;
+    }
+    void* p = nullptr;
+    hipError_t st = hipMalloc(&p, bytes);
+    if (st != hipSuccess) return n->fail(std::string("hipMalloc: ") + hipGetErrorString(st));
+    if (n->pcursor < n->pallocs.size()) {
+        (void)hipFree(n->pallocs[n->pcursor].first);
+        n->pallocs[n->pcursor] = {p, bytes};
+    } else {
+        n->pallocs.push_back({p, bytes});
+    }
+    ++n->pcursor;
+    *out = static_cast<T*>(p);
+    return 0;
+}
+
+// uploads are queued on the null stream from a staging copy that lives until the end of ao_net_finalize
 static int upload(ao_net* n, float** dst, const std::vector<float>& src) {
-    if (net_alloc(n, dst, src.size())) return 1;
+    if (param_alloc(n, dst, src.size())) return 1;
     NET_HIP(n, hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
@@ -574,6 +601,7 @@ void ao_net_destroy(ao_net* n) {
     hipSetDevice(n->device);
     hipDeviceSynchronize();
     for (void* p : n->allocs) hipFree(p);
+    for (auto& pa : n->pallocs) hipFree(pa.first);
     for (auto e : n->ev0) hipEventDestroy(e);
     for (auto e : n->ev1) hipEventDestroy(e);
     delete n;
@@ -654,13 +682,11 @@ static void pack_conv_h(const std::vector<float>& w, int cout, int cin, int s, s
 
 int ao_net_finalize(ao_net* n) {
     NET_HIP(n, hipSetDevice(n->device));
-    NET_HIP(n, hipDeviceSynchronize());
-    for (void* p : n->allocs) hipFree(p);
-    n->allocs.clear();
+    NET_HIP(n, hipDeviceSynchronize());   // nothing may still read the buffers that are overwritten below
+    n->pcursor = 0;
     n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
     n->convh_wh.clear(); n->convh_wl.clear(); n->convh_sc.clear();
-    n->ws_boards = 0;
-    if (net_alloc(n, &n->d_status, 4)) return 1;
+    if (param_alloc(n, &n->d_status, 4)) return 1;
     NET_HIP(n, hipMemset(n->d_status, 0, 16));
     const int P = n->planes, A = n->A;
     auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
@@ -713,17 +739,14 @@ int ao_net_finalize(ao_net* n) {
             std::vector<float> sc, sh;
             if (fold_bn(n, bname, P, &sc, &sh)) return 1;
             for (float& v : sc) v = std::ldexp(v, -sft);
-            void *dh = nullptr, *dl = nullptr;
+            uint16_t *dh = nullptr, *dl = nullptr;
             float* dsc = nullptr;
-            NET_HIP(n, hipMalloc(&dh, hi.size() * 2));
-            n->allocs.push_back(dh);
-            NET_HIP(n, hipMalloc(&dl, lo.size() * 2));
-            n->allocs.push_back(dl);
+            if (param_alloc(n, &dh, hi.size()) || param_alloc(n, &dl, lo.size())) return 1;
             NET_HIP(n, hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
             NET_HIP(n, hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
             if (upload(n, &dsc, sc)) return 1;
-            n->convh_wh.push_back(static_cast<uint4*>(dh));
-            n->convh_wl.push_back(static_cast<uint4*>(dl));
+            n->convh_wh.push_back(reinterpret_cast<uint4*>(dh));
+            n->convh_wl.push_back(reinterpret_cast<uint4*>(dl));
             n->convh_sc.push_back(dsc);
         }
     }

@@ -12,7 +12,8 @@ Differences by design:
   * self_play(n) plays its n games side by side (G = n slots of one engine, finished slots are
     refilled) instead of one after another. Episode e gets its own np.random stream seeded
     SEED + e (the reference draws all games from one stream); with n == 1 the process-global
-    np.random state is used, which reproduces `np.random.seed(s); main.self_play(1)` exactly.
+    np.random state is used, which reproduces `np.random.seed(s); main.self_play(1)` exactly, and
+    self_play(n, single_stream=True) is the reference's sequential one-stream schedule for any n.
   * under torch.distributed (one process per GPU) episodes are sharded e % world == rank, train()
     agrees on the mini-batch count and all-reduces the flattened gradient once per mini-batch
     (parallel.py), and run() plays one game PER RANK in the iterations after the first.
@@ -123,29 +124,12 @@ def release_engine():
         _engine = None
 
 
-def self_play(n_selfplay, seeds=None):
-    """Plays n_selfplay episodes and appends their samples to cur_memory / rep_memory exactly as the
-    reference does: per episode, plies in chronological order, (state [C,B,B] f64, pi [A] f64, z)."""
-    global _episodes_played
-    if Agent is None:
-        configure()
-    if hasattr(Agent.model, "eval"):
-        Agent.model.eval()
-    rank, world = parallel.world()
-    episodes = parallel.shard_games(n_selfplay, rank, world)
-    first_episode = _episodes_played
-    _episodes_played += n_selfplay                        # identical on every rank, shard or no shard
-    if not episodes:
-        Agent.reset()
-        return
-    use_global = (n_selfplay == 1 and seeds is None and world == 1)
+def _play_episodes(episodes, use_global, seed_of):
+    """Plays the listed episodes on one engine (G = min(len, MAX_CONCURRENT) slots, finished slots refilled).
+    Returns ({episode: moves}, {episode: [pi per ply]}, {episode: win_index})."""
     G = min(len(episodes), MAX_CONCURRENT)
     eng = _get_engine(G)
     eng.reset()
-
-    def seed_of(ep):
-        return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
-
     slot_ep = np.full(G, -1, np.int64)
     queue = list(episodes)
     moves = {}
@@ -195,6 +179,42 @@ def self_play(n_selfplay, seeds=None):
     if use_global:
         mt, pos, hg, gs = eng.get_rng_state(0)
         np.random.set_state(('MT19937', mt, pos, hg, gs))
+    return moves, pis, wins
+
+
+def self_play(n_selfplay, seeds=None, single_stream=False):
+    """Plays n_selfplay episodes and appends their samples to cur_memory / rep_memory exactly as the
+    reference does: per episode, plies in chronological order, (state [C,B,B] f64, pi [A] f64, z).
+
+    single_stream=True is the reference's own schedule for n_selfplay > 1 (main.py:136-142): the episodes are
+    played ONE AFTER ANOTHER and all draw from the process-global np.random stream, so
+    `np.random.seed(s); self_play(n, single_stream=True)` reproduces the reference's memory bit for bit (gv9) --
+    at one game's speed. The default plays the episodes side by side with per-episode streams."""
+    global _episodes_played
+    if Agent is None:
+        configure()
+    if hasattr(Agent.model, "eval"):
+        Agent.model.eval()
+    rank, world = parallel.world()
+    if single_stream and world > 1:
+        raise ValueError("single_stream self-play is the reference's sequential schedule: one process only")
+    episodes = parallel.shard_games(n_selfplay, rank, world)
+    first_episode = _episodes_played
+    _episodes_played += n_selfplay                        # identical on every rank, shard or no shard
+    if not episodes:
+        Agent.reset()
+        return
+
+    def seed_of(ep):
+        return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
+
+    if single_stream or (n_selfplay == 1 and seeds is None and world == 1):
+        moves, pis, wins = {}, {}, {}
+        for ep in episodes:                               # sequential, each on the global stream where the last left it
+            m, p, w = _play_episodes([ep], True, seed_of)
+            moves.update(m); pis.update(p); wins.update(w)
+    else:
+        moves, pis, wins = _play_episodes(episodes, False, seed_of)
 
     # results and samples in episode order (main.py:201-227)
     for ep in episodes:

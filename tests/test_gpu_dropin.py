@@ -86,15 +86,18 @@ def test_self_play_single_episode_matches_reference_memory(oracle):
     produced them (tests/golden/gv9, captured from main.self_play with the same stub model)."""
     import alpha_omok_amd.main as main
     g = load_golden("gv9_self_play_memory")
-    for ci in range(2):
+    for ci in range(int(g["ncases"])):
         B, S, mode, seed = g["c%d_cfg" % ci].tolist()
+        n_ep = int(g["c%d_episodes" % ci])
         main.PRINT_SELFPLAY = False
         main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, mode), seed=0)
         main.cur_memory.clear()
         main.rep_memory.clear()
         main.reset_iter(main.result, main.cur_memory)
         np.random.seed(seed)
-        main.self_play(1)
+        # one episode: the default path; three episodes: the reference's sequential one-stream schedule (opt-in)
+        main.self_play(n_ep, single_stream=(n_ep > 1))
+        assert np.random.get_state()[2] == int(g["c%d_mt_pos" % ci])
         cm = list(main.cur_memory)
         assert len(cm) == len(g["c%d_z" % ci])
         np.testing.assert_array_equal(np.stack([m[0] for m in cm]).astype(np.float32), g["c%d_state" % ci])

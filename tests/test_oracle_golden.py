@@ -218,3 +218,35 @@ def test_gv13_head_to_head_matches_reference(oracle):
             pa.reset()
             pb.reset()
             enemy_turn ^= 1
+
+
+def test_gv9_self_play_memory_incl_several_episodes_on_one_stream(oracle):
+    """main.self_play(n) of the reference (main.py:122-250): n episodes one after another on ONE np.random stream
+    (the agent is reset between episodes, the stream is not). Oracle agent driven the same way against gv9's
+    cur_memory (pi and z per ply, stream position at the end); c2 has three episodes."""
+    g = load_golden("gv9_self_play_memory")
+    for ci in range(int(g["ncases"])):
+        B, S, mode, seed = g["c%d_cfg" % ci].tolist()
+        ag = oracle.Agent(B, S, 5, noise=True, evaluator="stub%d" % mode)
+        ag.seed(seed)
+        want_pi, want_z = g["c%d_pi" % ci], g["c%d_z" % ci]
+        k = 0
+        res = [0, 0, 0]
+        for ep in range(int(g["c%d_episodes" % ci])):
+            root = (0,)
+            start = k
+            while True:
+                pi, vis, pol = ag.get_pi(root, 1 if len(root) - 1 < 6 else 0)
+                np.testing.assert_array_equal(pi, want_pi[k], err_msg="case %d episode %d ply %d" % (ci, ep, k - start))
+                root = root + (int(ag.rng.choice_p(pi)),)
+                k += 1
+                win = oracle.check_win(oracle.get_board(list(root)[1:], B), 5)
+                if win != 0:
+                    break
+            res[win - 1] += 1
+            zb = {1: 1.0, 2: -1.0, 3: 0.0}[win]
+            for t in range(start, k):
+                assert want_z[t] == (zb if (t - start) % 2 == 0 else -zb)
+            ag.reset()
+        assert k == len(want_z) and res == g["c%d_result" % ci].tolist()
+        assert ag.rng.pos == int(g["c%d_mt_pos" % ci])

@@ -379,7 +379,8 @@ def gv9():
     ref_main.PRINT_SELFPLAY = False
     ref_agents.PRINT_MCTS = False
     out = {}
-    for ci, (S, mode, seed) in enumerate(((30, 1, 5), (24, 0, 9))):
+    # (sims, stub, seed, episodes): the third case is main.py:136-142's loop over several episodes on ONE stream
+    for ci, (S, mode, seed, n_ep) in enumerate(((30, 1, 5, 1), (24, 0, 9, 1), (20, 1, 31, 3))):
         ref_main.Agent = ref_agents.ZeroAgent(9, S, 5, noise=True)
         ref_main.Agent.model = StubModel(mode)
         ref_main.cur_memory.clear()
@@ -387,9 +388,11 @@ def gv9():
         for k in ref_main.result:
             ref_main.result[k] = 0
         np.random.seed(seed)
-        ref_main.self_play(1)
+        ref_main.self_play(n_ep)
         cm = list(ref_main.cur_memory)
         out["c%d_cfg" % ci] = np.array([9, S, mode, seed], np.int32)
+        out["c%d_episodes" % ci] = np.array(n_ep, np.int32)
+        out["c%d_mt_pos" % ci] = np.array(np.random.get_state()[2], np.int64)
         out["c%d_state" % ci] = np.stack([m[0] for m in cm]).astype(np.float32)
         out["c%d_pi" % ci] = np.stack([m[1] for m in cm])
         out["c%d_z" % ci] = np.array([m[2] for m in cm])
@@ -398,6 +401,7 @@ def gv9():
         rm = list(ref_main.rep_memory)
         out["c%d_rep_pi_head" % ci] = np.stack([m[1] for m in rm[:16]])
         out["c%d_rep_state_head" % ci] = np.stack([m[0] for m in rm[:16]]).astype(np.float32)
+    out["ncases"] = np.array(3)
     save("gv9_self_play_memory", **out)
 
 
