@@ -34,11 +34,22 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half8 buf_ld_h8(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// Cache-policy bits of the three activation streams (aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1),
+// compile-time knobs for the A/B runs in profiles/r2h_trunk16h_cache_policy_ab.txt
+#ifndef AO_AUX_RES
+#define AO_AUX_RES 0     // residual loads of the conv2 epilogue
+#endif
+#ifndef AO_AUX_ST
+#define AO_AUX_ST 0      // activation stores of every epilogue
+#endif
+#ifndef AO_AUX_STAGE
+#define AO_AUX_STAGE 0   // LDS-direct loads that stage the input rows
+#endif
 __device__ __forceinline__ half4 buf_ld_h4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    return __builtin_bit_cast(half4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AO_AUX_RES));
 }
 __device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, AO_AUX_ST);
 }
 
 #ifdef AO_PROF
@@ -239,7 +250,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
             const int f = tile + NT * k;
             if (f < NFR)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
-                                                         (py(0) * NFR + f) * 1024, 0, 0);
+                                                         (py(0) * NFR + f) * 1024, 0, AO_AUX_STAGE);
         }
     }
     AO_T(t_a2);
@@ -275,7 +286,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                         if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
                         else
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
-                                                                     16, lane16, (py(yn) * NFR + f) * 1024, 0, 0);
+                                                                     16, lane16, (py(yn) * NFR + f) * 1024, 0, AO_AUX_STAGE);
                     }
                 }
             }
@@ -294,6 +305,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                     // consecutive MFMAs hit different accumulators
 #pragma unroll
                     for (int pr = 0; pr < NPR; ++pr) {
+                        if (BITS && pr == 2) continue;   // bit planes are 0 / 1: their low halves are zero, no xl * wh product
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
                             const int i = xi - dx + 1;
@@ -432,7 +444,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
                     xb[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(y * BW + xin, rest));
                 } else {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + f * 64), 16,
-                                                             lane16, ((y * BW + xin) * NCI * 2 + rest) * 1024, 0, 0);
+                                                             lane16, ((y * BW + xin) * NCI * 2 + rest) * 1024, 0, AO_AUX_STAGE);
                 }
             }
         }
@@ -507,6 +519,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
                     }
 #pragma unroll
                     for (int pr = 0; pr < NPR; ++pr) {
+                        if (BITS && pr == 2) continue;   // (see trunk_h_layer)
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
                             const int i = HALO ? j - dx : j - dx + 1;   // output cell of the tile fed through tap column dx
