@@ -13,6 +13,7 @@
 #include <map>
 #include <type_traits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/omok_hip.h"
@@ -689,61 +690,76 @@ int ao_net_finalize(ao_net* n) {
     if (param_alloc(n, &n->d_status, 4)) return 1;
     NET_HIP(n, hipMemset(n->d_status, 0, 16));
     const int P = n->planes, A = n->A;
-    auto add_conv = [&](const std::string& wname, const std::string& bnname, int cin, int cqi) -> int {
-        const std::vector<float>* w;
-        if (get_param(n, wname, static_cast<size_t>(P) * cin * 9, &w)) return 1;
-        std::vector<float> sc, sh;
-        if (fold_bn(n, bnname, P, &sc, &sh)) return 1;
-        float *dw, *dsc, *dsh;
-        if (upload(n, &dw, pack_conv(*w, P, cin, cqi)) || upload(n, &dsc, sc) || upload(n, &dsh, sh)) return 1;
-        n->conv_w.push_back(dw); n->conv_sc.push_back(dsc); n->conv_sh.push_back(dsh);
-        return 0;
+    // The repacking of the conv weights (strided scatters over 147 k weights per layer and layout) is the bulk of a
+    // re-export: it runs on one host thread per layer, the uploads follow in a fixed order (param_alloc's sequence).
+    const int nl = 1 + 2 * n->nb;
+    const bool h16 = h16_supported(n);
+    struct LayerPack {
+        const std::vector<float>* w = nullptr;
+        std::string bn;
+        int cin = 0;
+        std::vector<float> w32, w16, w1;   // fp32 layouts: [tap][cq][cout][4] for nchq32 / CQ (and conv1: nchq16, nchq1)
+        std::vector<uint16_t> hi, lo;      // split-fp16 layout
+        int sft = 0;
     };
-    if (add_conv("conv1.weight", "bn1", n->C, n->nchq32)) return 1;
+    std::vector<LayerPack> pk(nl);
+    for (int l = 0; l < nl; ++l) {
+        const std::string pre = "layers." + std::to_string(l ? (l - 1) / 2 : 0);
+        const std::string cname = l == 0 ? std::string("conv1.weight") : pre + ((l & 1) ? ".conv1.weight" : ".conv2.weight");
+        pk[l].bn = l == 0 ? std::string("bn1") : pre + ((l & 1) ? ".bn1" : ".bn2");
+        pk[l].cin = l == 0 ? n->C : P;
+        if (get_param(n, cname, static_cast<size_t>(P) * pk[l].cin * 9, &pk[l].w)) return 1;
+    }
     {
-        const std::vector<float>* w;
-        if (get_param(n, "conv1.weight", static_cast<size_t>(P) * n->C * 9, &w)) return 1;
-        if (upload(n, &n->conv0_w16, pack_conv(*w, P, n->C, n->nchq16))) return 1;
-        if (upload(n, &n->conv0_w1, pack_conv(*w, P, n->C, n->nchq1))) return 1;
+        std::vector<std::thread> th;
+        for (int l = 0; l < nl; ++l)
+            th.emplace_back([&, l]() {
+                LayerPack& k = pk[l];
+                const std::vector<float>& w0 = *k.w;
+                k.w32 = pack_conv(w0, P, k.cin, l == 0 ? n->nchq32 : n->CQ);
+                if (l == 0) {
+                    k.w16 = pack_conv(w0, P, n->C, n->nchq16);
+                    k.w1 = pack_conv(w0, P, n->C, n->nchq1);
+                }
+                if (!h16) return;
+                // conv1: input channels zero-padded to one 32-channel block
+                std::vector<float> wpad;
+                const std::vector<float>* w = &w0;
+                const int cinp = l == 0 ? 32 : P;
+                if (l == 0) {
+                    wpad.assign(static_cast<size_t>(P) * 32 * 9, 0.f);
+                    for (int co = 0; co < P; ++co)
+                        for (int ci = 0; ci < n->C; ++ci)
+                            for (int t = 0; t < 9; ++t)
+                                wpad[(static_cast<size_t>(co) * 32 + ci) * 9 + t] = w0[(static_cast<size_t>(co) * n->C + ci) * 9 + t];
+                    w = &wpad;
+                }
+                float mx = 0.f;
+                for (float v : *w) mx = std::max(mx, std::fabs(v));
+                // power-of-two pre-scale: largest |w| lands in [4, 8), so the low halves are normal fp16 numbers
+                k.sft = (mx > 0.f && std::isfinite(mx)) ? 2 - static_cast<int>(std::floor(std::log2(mx))) : 0;
+                pack_conv_h(*w, P, cinp, k.sft, &k.hi, &k.lo);
+            });
+        for (auto& t : th) t.join();
     }
-    for (int i = 0; i < n->nb; ++i) {
-        const std::string pre = "layers." + std::to_string(i);
-        if (add_conv(pre + ".conv1.weight", pre + ".bn1", P, n->CQ)) return 1;
-        if (add_conv(pre + ".conv2.weight", pre + ".bn2", P, n->CQ)) return 1;
+    for (int l = 0; l < nl; ++l) {
+        std::vector<float> sc, sh;
+        if (fold_bn(n, pk[l].bn, P, &sc, &sh)) return 1;
+        float *dw, *dsc, *dsh;
+        if (upload(n, &dw, pk[l].w32) || upload(n, &dsc, sc) || upload(n, &dsh, sh)) return 1;
+        n->conv_w.push_back(dw); n->conv_sc.push_back(dsc); n->conv_sh.push_back(dsh);
+        if (l == 0 && (upload(n, &n->conv0_w16, pk[0].w16) || upload(n, &n->conv0_w1, pk[0].w1))) return 1;
     }
-    if (h16_supported(n)) {
-        for (int l = 0; l <= 2 * n->nb; ++l) {
-            const std::string pre = "layers." + std::to_string(l ? (l - 1) / 2 : 0);
-            const std::string cname = l == 0 ? std::string("conv1.weight") : pre + ((l & 1) ? ".conv1.weight" : ".conv2.weight");
-            const std::string bname = l == 0 ? std::string("bn1") : pre + ((l & 1) ? ".bn1" : ".bn2");
-            const int cin = l == 0 ? n->C : P;
-            const std::vector<float>* w0;
-            if (get_param(n, cname, static_cast<size_t>(P) * cin * 9, &w0)) return 1;
-            // conv1: input channels zero-padded to one 32-channel block
-            std::vector<float> wpad;
-            const std::vector<float>* w = w0;
-            const int cinp = l == 0 ? 32 : P;
-            if (l == 0) {
-                wpad.assign(static_cast<size_t>(P) * 32 * 9, 0.f);
-                for (int co = 0; co < P; ++co)
-                    for (int ci = 0; ci < n->C; ++ci)
-                        for (int t = 0; t < 9; ++t) wpad[(static_cast<size_t>(co) * 32 + ci) * 9 + t] = (*w0)[(static_cast<size_t>(co) * n->C + ci) * 9 + t];
-                w = &wpad;
-            }
-            float mx = 0.f;
-            for (float v : *w) mx = std::max(mx, std::fabs(v));
-            // power-of-two pre-scale: largest |w| lands in [4, 8), so the low halves are normal fp16 numbers
-            const int sft = (mx > 0.f && std::isfinite(mx)) ? 2 - static_cast<int>(std::floor(std::log2(mx))) : 0;
-            std::vector<uint16_t> hi, lo;
-            pack_conv_h(*w, P, cinp, sft, &hi, &lo);
+    if (h16) {
+        for (int l = 0; l < nl; ++l) {
             std::vector<float> sc, sh;
-            if (fold_bn(n, bname, P, &sc, &sh)) return 1;
-            for (float& v : sc) v = std::ldexp(v, -sft);
+            if (fold_bn(n, pk[l].bn, P, &sc, &sh)) return 1;
+            for (float& v : sc) v = std::ldexp(v, -pk[l].sft);
             uint16_t *dh = nullptr, *dl = nullptr;
             float* dsc = nullptr;
-            if (param_alloc(n, &dh, hi.size()) || param_alloc(n, &dl, lo.size())) return 1;
-            NET_HIP(n, hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
-            NET_HIP(n, hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+            if (param_alloc(n, &dh, pk[l].hi.size()) || param_alloc(n, &dl, pk[l].lo.size())) return 1;
+            NET_HIP(n, hipMemcpy(dh, pk[l].hi.data(), pk[l].hi.size() * 2, hipMemcpyHostToDevice));
+            NET_HIP(n, hipMemcpy(dl, pk[l].lo.data(), pk[l].lo.size() * 2, hipMemcpyHostToDevice));
             if (upload(n, &dsc, sc)) return 1;
             n->convh_wh.push_back(reinterpret_cast<uint4*>(dh));
             n->convh_wl.push_back(reinterpret_cast<uint4*>(dl));
