@@ -275,6 +275,8 @@ def main():
                     help="0 auto, 1 layer kernels, 2 group-resident fp32-MFMA trunk, 3 per-board, 4 row-chunked, "
                          "5 group-resident split-fp16 trunk")
     ap.add_argument("--no-fp32-compare", action="store_true", help="skip the extra fp32-MFMA-trunk measurement")
+    ap.add_argument("--no-ten-block", action="store_true",
+                    help="skip the extra measurement with the reference's default net (N_BLOCKS = 10, main.py:33)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="(kept for compatibility: the all-cores sample is on by default)")
     ap.add_argument("--train-step", choices=("auto", "on", "off"), default="auto",
                     help="BASELINE configs[3]: after every step (= refill cycle) one batch-32 training step per GPU "
@@ -327,9 +329,9 @@ def main():
     ply = np.zeros(G, np.int64)
     counters = dict(moves=0, games=0, levels=0, evaluated=0, terminal=0)
 
-    def step(count):
+    def step(count, use_net=None):
         tau = (ply < 6).astype(np.int8)  # main.py:150-153 TAU_THRES
-        eng.search(net, tau=tau)
+        eng.search(use_net if use_net is not None else net, tau=tau)
         st = eng.search_stats()
         act, win = eng.play()
         ply[:] += 1
@@ -508,6 +510,26 @@ def main():
             except Exception as e:
                 out["fp32_mfma_trunk"] = {"value": None, "error": repr(e)}
             net.set_mode(args.trunk_mode)
+        if world == 1 and args.blocks != 10 and not args.no_ten_block:
+            # the reference's own default network (main.py:33 N_BLOCKS = 10) on the same workload, two steps
+            try:
+                torch.manual_seed(0)
+                m10 = PVNet(10, 5, args.planes, B)
+                m10.eval()
+                net10 = m10.to_native(local)
+                step(False, net10)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step(False, net10)
+                fence()
+                d1 = time.perf_counter() - t1
+                out["ten_block_net"] = {"workload": "same games, random-init 10-block/%d-ch PVNet (the reference's default, main.py:33)" % args.planes,
+                                        "value": 2 * G / d1, "unit": "move-decisions/s", "ms_per_step": d1 / 2 * 1e3,
+                                        "flops_per_move_algorithmic": S * eval_flops(B, 5, args.planes, 10)}
+                net10.close()
+            except Exception as e:
+                out["ten_block_net"] = {"value": None, "error": repr(e)}
         if world == 1 and G > 1 and not args.no_single_game:
             # BASELINE configs[1] beside the headline: ONE game, 400 sims/move, same network
             # (latency path: per-board conv kernels, no concurrency to hide behind)
