@@ -28,9 +28,18 @@ def elo(player_elo, enemy_elo, p_winscore, e_winscore):
     return player_elo, enemy_elo
 
 
-def play_match(player, enemy, board_size, enemy_turn, max_plies=None):
-    """One game; `enemy_turn` (0 black / 1 white) is the colour of `enemy` (eval_main.py:229-300).
-    Returns (win_index, moves)."""
+def _is_zero(agent):
+    """ZeroAgent-style get_pi(root_id, tau) vs the rollout agents' get_pi(root_id, board, turn, tau)
+    (the isinstance test of eval_main.py:139,146)."""
+    inner = getattr(agent, "ag", agent)
+    return not hasattr(inner, "_MODE")
+
+
+def play_match(player, enemy, board_size, enemy_turn, max_plies=None, monitor=None):
+    """One game; `enemy_turn` (0 black / 1 white) is the colour of `enemy` (eval_main.py:229-300). Players may be
+    ZeroAgents or the rollout agents (PUCTAgent / UCTAgent); when the PLAYER is a rollout agent and a `monitor`
+    ZeroAgent is given, the monitor searches the same root right after the player, as Evaluator.get_action does
+    (eval_main.py:141-144: its tie-breaks come out of the shared stream). Returns (win_index, moves)."""
     win_mark = 3 if board_size == 3 else 5
     root_id = (0,)
     turn = 0
@@ -38,7 +47,12 @@ def play_match(player, enemy, board_size, enemy_turn, max_plies=None):
     moves = []
     while win_index == 0:
         agent = enemy if turn == enemy_turn else player
-        pi = agent.get_pi(root_id, tau=0)
+        if _is_zero(agent):
+            pi = agent.get_pi(root_id, tau=0)
+        else:
+            pi = agent.get_pi(root_id, utils.get_board(root_id, board_size), turn, tau=0)
+            if agent is player and monitor is not None:
+                monitor.get_pi(root_id, tau=0)
         _, action_index = utils.argmax_onehot(pi)
         root_id = root_id + (int(action_index),)
         moves.append(int(action_index))
@@ -48,6 +62,8 @@ def play_match(player, enemy, board_size, enemy_turn, max_plies=None):
             break
     player.reset()
     enemy.reset()
+    if monitor is not None:
+        monitor.reset()
     return win_index, moves
 
 

@@ -214,6 +214,37 @@ def test_evaluate_matches_reference_eval_main(oracle):
         np.testing.assert_allclose([pe, ee], g["c%d_elo" % ci][-1], rtol=0, atol=1e-9)
 
 
+def test_mixed_match_rollout_player_monitor_and_zero_enemy_match_reference(oracle):
+    """eval_main.py:137-151 with a rollout PLAYER (PUCTAgent / UCTAgent), the monitor ZeroAgent that searches the same
+    root right after it, and a ZeroAgent enemy -- three engines taking turns on the process-global stream. Moves,
+    winner, the monitor's visit counts and the stream position after the match equal the reference's (gv13 m-cases)."""
+    from alpha_omok_amd import agents, evaluate
+    agents.PRINT_MCTS = False
+    g = load_golden("gv13_eval_head_to_head")
+    for mi in range(int(g["nmixed"])):
+        B, mode, SP, SE, SM, me, mm, seed, enemy_turn = g["m%d_cfg" % mi].tolist()
+        player = (agents.PUCTAgent if mode == 0 else agents.UCTAgent)(B, SP)
+        enemy = agents.ZeroAgent(B, SE, 5, noise=False)
+        enemy.model = StubModel(oracle, me)
+        monitor = agents.ZeroAgent(B, SM, 5, noise=False)
+        monitor.model = StubModel(oracle, mm)
+        seen = []
+        orig = monitor.get_pi
+
+        def spy(root_id, tau, orig=orig, seen=seen, monitor=monitor):
+            pi = orig(root_id, tau)
+            seen.append(monitor.get_visit().copy())
+            return pi
+
+        monitor.get_pi = spy
+        np.random.seed(seed)
+        win, moves = evaluate.play_match(player, enemy, B, enemy_turn, monitor=monitor)
+        assert moves == g["m%d_moves" % mi].tolist(), mi
+        assert win == int(g["m%d_win" % mi])
+        assert np.random.get_state()[2] == int(g["m%d_mt_pos" % mi][-1])
+        np.testing.assert_array_equal(np.stack(seen), g["m%d_monitor_visit" % mi])
+
+
 def test_evaluate_batched_equals_sequential_matches(oracle):
     """All matches of eval_main.py:204-333 concurrently (two G = n_match engines, one ao_set_roots launch per
     side and ply): match i must be exactly `np.random.seed(seed + i); play_match(...)` with the colours of

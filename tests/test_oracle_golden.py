@@ -250,3 +250,32 @@ def test_gv9_self_play_memory_incl_several_episodes_on_one_stream(oracle):
             ag.reset()
         assert k == len(want_z) and res == g["c%d_result" % ci].tolist()
         assert ag.rng.pos == int(g["c%d_mt_pos" % ci])
+
+
+def test_gv13_mixed_matches_rollout_player_with_monitor(oracle):
+    """eval_main.py:137-151 with a rollout PLAYER: PUCT / UCT search, then the monitor ZeroAgent on the same root, then
+    the ZeroAgent enemy's reply -- all on one stream. Oracle rollout search + two oracle agents against the reference."""
+    g = load_golden("gv13_eval_head_to_head")
+    for mi in range(int(g["nmixed"])):
+        B, mode, SP, SE, SM, me, mm, seed, enemy_turn = g["m%d_cfg" % mi].tolist()
+        enemy = oracle.Agent(B, SE, 5, noise=False, evaluator="stub%d" % me)
+        monitor = oracle.Agent(B, SM, 5, noise=False, evaluator="stub%d" % mm)
+        shared = oracle.Rng(seed)
+        root = (0,)
+        k = 0
+        for t, mv in enumerate(g["m%d_moves" % mi]):
+            if (t % 2) != enemy_turn:
+                pi, stat, act, nodes = oracle.rollout_search(mode, B, SP, root, shared)
+                monitor.rng.set_state(shared.state_words(), shared.pos)
+                _, mvis, _ = monitor.get_pi(root, 0)
+                shared.set_state(monitor.rng.state_words(), monitor.rng.pos)
+                np.testing.assert_array_equal(mvis, g["m%d_monitor_visit" % mi][k])
+                k += 1
+            else:
+                enemy.rng.set_state(shared.state_words(), shared.pos)
+                pi, _, _ = enemy.get_pi(root, 0)
+                shared.set_state(enemy.rng.state_words(), enemy.rng.pos)
+            assert int(np.argmax(pi)) == int(mv), (mi, t)
+            assert shared.pos == int(g["m%d_mt_pos" % mi][t]), (mi, t)
+            root = root + (int(mv),)
+        assert oracle.check_win(oracle.get_board(list(root)[1:], B), 5) == int(g["m%d_win" % mi])

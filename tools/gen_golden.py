@@ -614,6 +614,43 @@ def gv13():
         out["c%d_win" % ci] = np.array(win_all, np.int32)
         out["c%d_elo" % ci] = np.array(elo_all, np.float64)
         out["c%d_result" % ci] = np.array([result[k] for k in ("Player", "Enemy", "Draw")], np.int32)
+    # mixed matches (eval_main.py:137-151): the player is a rollout agent -> get_pi(root_id, board, turn, tau) and the
+    # MONITOR ZeroAgent searches the same root right after it (its draws and evaluations sit in the shared stream);
+    # the enemy is a ZeroAgent. One match per case: (player kind, S_player, S_enemy, S_monitor, stub_e, stub_m, seed, enemy_turn)
+    mixed = (("puct", 40, 24, 16, 1, 0, 77, 1), ("uct", 30, 20, 12, 0, 1, 78, 0))
+    for mi, (kind, SP, SE, SM, me, mm, seed, enemy_turn) in enumerate(mixed):
+        B = 9
+        ev = ref_eval.Evaluator()
+        ev.player = (ref_agents.PUCTAgent if kind == "puct" else ref_agents.UCTAgent)(B, SP)
+        ev.enemy = ref_agents.ZeroAgent(B, SE, 5, noise=False)
+        ev.enemy.model = StubModel(me)
+        ev.monitor = ref_agents.ZeroAgent(B, SM, 5, noise=False)
+        ev.monitor.model = StubModel(mm)
+        np.random.seed(seed)
+        env = ref_eval.game.GameState('text')
+        board = np.zeros([B, B])
+        root_id = (0,)
+        win_index = 0
+        turn = 0
+        moves, poss, mvis = [], [], []
+        while win_index == 0:
+            with contextlib.redirect_stdout(io.StringIO()):
+                action, action_index = ev.get_action(root_id, board, turn, enemy_turn)
+            mover = ev.player if turn != enemy_turn else ev.enemy
+            if turn != enemy_turn:
+                mvis.append(ev.monitor.get_visit().copy())
+            root_id = mover.root_id + (action_index,)
+            with contextlib.redirect_stdout(io.StringIO()):
+                board, check_valid_pos, win_index, turn, _ = env.step(action)
+                (ev.enemy if turn == enemy_turn else ev.player).del_parents(root_id)
+            moves.append(int(action_index))
+            poss.append(int(np.random.get_state()[2]))
+        out["m%d_cfg" % mi] = np.array([B, 0 if kind == "puct" else 1, SP, SE, SM, me, mm, seed, enemy_turn], np.int32)
+        out["m%d_moves" % mi] = np.array(moves, np.int32)
+        out["m%d_mt_pos" % mi] = np.array(poss, np.int64)
+        out["m%d_monitor_visit" % mi] = np.stack(mvis).astype(np.float32)
+        out["m%d_win" % mi] = np.array(win_index, np.int32)
+    out["nmixed"] = np.array(len(mixed))
     out["ncases"] = np.array(len(cases))
     save("gv13_eval_head_to_head", **out)
 
