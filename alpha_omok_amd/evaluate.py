@@ -67,14 +67,14 @@ def play_match(player, enemy, board_size, enemy_turn, max_plies=None, monitor=No
     return win_index, moves
 
 
-def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo=1500.0, return_games=False):
+def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo=1500.0, return_games=False, monitor=None):
     """n_match games with the colours swapped every game (eval_main.py:213-333). Returns the result
     tally and the final ELO pair (and the [(win_index, moves)] list with return_games)."""
     result = {'Player': 0, 'Enemy': 0, 'Draw': 0}
     enemy_turn = 1
     games = []
     for _ in range(n_match):
-        win_index, moves = play_match(player, enemy, board_size, enemy_turn)
+        win_index, moves = play_match(player, enemy, board_size, enemy_turn, monitor=monitor)
         games.append((win_index, moves))
         if win_index == 3:
             result['Draw'] += 1
