@@ -54,6 +54,8 @@ struct ao_engine {
     std::vector<int32_t> h_walk;     // staging of ao_set_root(s): [G][A] moves + games, counts, prev_known, status
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
     uint8_t* d_planes_u8 = nullptr;                       // bit planes [Gp][u8_row] (input of the split-fp16 kernels)
+    int32_t* d_row = nullptr;                             // [G] batch row of each game in ao_search (active games packed)
+    std::vector<int32_t> h_row;
     size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
     std::vector<std::vector<int32_t>> moves;
@@ -216,7 +218,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &e->d_policy, static_cast<size_t>(Gp) * A) || dev_alloc(e, &e->d_value, Gp))
         return 1;
     p.u8_row = A <= 128 ? 128 : 256;
-    if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row)) return 1;
+    if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, G)) return 1;
+    p.row_of_game = nullptr;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
     p.batch_u8 = nullptr;
     e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
@@ -611,8 +614,18 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
     std::string why;
     if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
     // the network announces the interleaved input layout it wants for a batch of G boards
+    if (ao_begin_move(e, active)) return 1;
+    // The network runs on the ACTIVE games only: they are packed to the front of the evaluation batch (row_of_game), so
+    // a move in which a third of the slots still plays -- the tail of main.self_play(n), one side of evaluate_batched,
+    // an uneven shard -- costs a third of the network time, and may take another kernel (net_plan for that many boards).
+    int rows = 0;
+    e->h_row.assign(e->G, 0);
+    for (int g = 0; g < e->G; ++g)
+        if (e->active[g]) e->h_row[g] = rows++;
+    if (rows == 0) return ao_end_move(e, tau, pi, visit, policy);
+    AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * e->G, hipMemcpyHostToDevice, e->stream));
     int in_kind = 1;
-    ao::net_plan(net, e->G, &e->tp.il_group, &e->tp.nchq, &in_kind);
+    ao::net_plan(net, rows, &e->tp.il_group, &e->tp.nchq, &in_kind);
     // The padding channels of the fp32 input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
     // encoder only writes the quads that hold planes (16 B per lane at a 2 KB stride are partial-line writes --
     // rocprof showed 152 MB of HBM writes per launch for a 42 MB batch). A change of layout re-zeroes the buffer.
@@ -623,13 +636,13 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
         e->il_group_zeroed = e->tp.il_group;
         e->il_nchq_zeroed = e->tp.nchq;
     }
-    if (ao_begin_move(e, active)) return 1;
     // select | net | expand+select | net | ... | expand(+idle select): one launch fewer per simulation
     // than the step-wise protocol, same device code (tree_device.hpp).
     ao::TreeParams p = e->tp;
     p.batch_nchw = nullptr;
     p.policy = e->d_policy;
     p.value = e->d_value;
+    p.row_of_game = e->d_row;
     p.nchq_live = (e->cfg.inplanes + 3) / 4;
     const float* net_in = p.batch_il;
     if (in_kind == 2) {
@@ -638,7 +651,7 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
         p.batch_il = nullptr;
     }
     auto one_sim = [&]() -> int {
-        if (ao::net_forward_il(net, net_in, e->G, e->d_policy, e->d_value, e->stream, in_kind))
+        if (ao::net_forward_il(net, net_in, rows, e->d_policy, e->d_value, e->stream, in_kind))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
         if (e->timing) {
             if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);

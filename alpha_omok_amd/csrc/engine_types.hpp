@@ -78,6 +78,8 @@ struct TreeParams {
     float* batch_nchw;    // [G][C][B][B] or null
     uint8_t* batch_u8;    // bit planes [G][u8_row] (byte per cell, bit q = plane q) or null: the split-fp16 network's input
     int u8_row;           // 128 (A <= 128) or 256
+    const int32_t* row_of_game;  // row of game g in the native network's batch (active games are packed to the front:
+                          // the network runs on the active games only), or null = g. Not used for batch_nchw / external p, v
     const float* policy;  // [G][A]
     const float* value;   // [G]
     // move results

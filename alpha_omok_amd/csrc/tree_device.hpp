@@ -315,6 +315,7 @@ struct MtDev {
 template <int NCH>
 __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s) {
     const int lane = lane_id();
+    const int row = p.row_of_game ? p.row_of_game[g] : g;   // batch row of the native network (active games packed)
     const int k = s.ply;
     const int stm = k & 1;           // 0: black to move
     const int C = p.C;
@@ -346,14 +347,14 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
         if (p.batch_u8) {
             unsigned bits = 0;
             for (int q = 0; q < C; ++q) bits |= (plane(q) != 0.f) ? (1u << q) : 0u;
-            p.batch_u8[static_cast<size_t>(g) * p.u8_row + cell] = static_cast<uint8_t>(bits);
+            p.batch_u8[static_cast<size_t>(row) * p.u8_row + cell] = static_cast<uint8_t>(bits);
         }
         if (p.batch_nchw) {
             for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = plane(q);
         }
         if (p.batch_il) {
-            const size_t grp = static_cast<size_t>(g / p.il_group);
-            const int b = g % p.il_group;
+            const size_t grp = static_cast<size_t>(row / p.il_group);
+            const int b = row % p.il_group;
             for (int cq = 0; cq < p.nchq_live; ++cq) {
                 const float4 v4 = make_float4(plane(4 * cq), plane(4 * cq + 1), plane(4 * cq + 2), plane(4 * cq + 3));
                 float4* dst = reinterpret_cast<float4*>(p.batch_il) +
@@ -623,12 +624,13 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
     const int newn = p.nodes_used[g];
     const int done = p.sims_done[g];
     PosR lp = pos_load(p.leaf_pos + g);
-    const float v_eval = p.value[g];
+    const int row = p.row_of_game ? p.row_of_game[g] : g;
+    const float v_eval = p.value[row];
     float pol[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
-        pol[c] = (cell < p.A) ? p.policy[static_cast<size_t>(g) * p.A + cell] : 0.f;
+        pol[c] = (cell < p.A) ? p.policy[static_cast<size_t>(row) * p.A + cell] : 0.f;
     }
     const int pn0 = (lane < p.maxd) ? p.path_node[pbase + lane] : 0;
     const int pe0 = (lane < p.maxd) ? static_cast<int>(p.path_edge[pbase + lane]) : 0;

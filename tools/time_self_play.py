@@ -1,0 +1,19 @@
+"""End-to-end main.self_play(n) timing (host bookkeeping, sample emission and augmentation included):
+    python tools/time_self_play.py [games] [sims] [blocks] [device_replay 0/1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from alpha_omok_amd import main
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+sims = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+dr = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+main.configure(board_size=9, n_mcts=sims, n_blocks=nb, seed=0, device_replay=dr)
+main.self_play(min(n, 64))            # warm-up: builds the engine, exports the net
+main.cur_memory.clear(); main.rep_memory.clear()
+t0 = time.perf_counter()
+main.self_play(n)
+dt = time.perf_counter() - t0
+moves = len(main.cur_memory)
+print("self_play(%d) @%d sims, %d blocks, device_replay=%s: %.1f s, %d move decisions = %.0f move-decisions/s, "
+      "%d replay entries" % (n, sims, nb, dr, dt, moves, moves / dt, len(main.rep_memory)))
