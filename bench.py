@@ -261,8 +261,8 @@ class TrainStep:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed move decisions per game slot (20 steps from ply 5 on: ~750 of 4096 games finish and are refilled inside the timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=400)
     ap.add_argument("--board", type=int, default=9)
