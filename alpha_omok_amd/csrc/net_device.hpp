@@ -1,6 +1,6 @@
 // net_device.hpp -- device code of the small-batch ("latency") network path, shared by the
-// per-layer kernels of net.hip (k_conv_cells, k_heads_board) and by the persistent single-game
-// search kernel (fused_small.hip).
+// per-layer kernels of net.hip (k_conv_cells, k_heads_board). (The persistent single-game search
+// kernel these were first shared with was measured slower and is not in the tree: DESIGN.md section 4.)
 //
 // Layout: per-board NHWC, act[board][cell][channel] as float4 channel quads. The CELLS of one
 // board are the MFMA N dimension:   D[cout 16][cell 16] += Wt[cout 16][k 4] * X[k 4][cell 16]

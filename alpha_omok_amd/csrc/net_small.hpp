@@ -13,7 +13,7 @@ namespace ao {
 // Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
 // ----------------------------------------------------------------------------------------------
 // NCQG = 16-channel k-steps per tap; NW = waves per tile (9: one tap each, 3: one tap row each).
-// The tile code is conv_cells_tile (net_device.hpp), shared with the persistent single-game kernel.
+// The tile code is conv_cells_tile (net_device.hpp).
 template <int BW, int NCQG, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                    const float4* __restrict__ scale, const float4* __restrict__ shift,

@@ -1,10 +1,9 @@
 // tree_device.hpp -- device code of the per-simulation tree work: selection (agents.py:134-168),
 // expansion + backup (agents.py:170-239), the per-game numpy-legacy MT19937 stream, the input
 // plane encoder (utils.py:139-168), legal-move order (utils.py:22-27, CPython set order) and
-// numpy's pairwise fp64 sum. One wavefront owns one game. Included by tree_kernels.hip (one
-// 64-thread block per game) and by fused_small.hip (wave 0 of a workgroup of the persistent
-// single-game search kernel); see tree_kernels.hip for the reference map and the arithmetic
-// contract.
+// numpy's pairwise fp64 sum. One wavefront owns one game. Included by tree_kernels.hip (one wave
+// per game, up to four games per workgroup) and by rollout.hip; see tree_kernels.hip for the
+// reference map and the arithmetic contract.
 #pragma once
 #include "engine_types.hpp"
 
@@ -17,8 +16,8 @@ __device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) 
 
 // Ordering point between the lanes of ONE wavefront that exchange data through LDS. The per-game
 // code is single-wave (LDS requests of a wave complete in order), so only the compiler has to be
-// kept from reordering; a workgroup barrier here would deadlock when the code runs as wave 0 of a
-// larger workgroup (fused_small.hip).
+// kept from reordering; a workgroup barrier here would deadlock when the waves of a workgroup run
+// different games (k_expand_select: four games per workgroup, each with its own control flow).
 __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
