@@ -23,11 +23,17 @@ def source_hash():
     """sha256 (16 hex digits) over the kernel sources and headers: ties a rocprofv3 counter summary under
     profiles/ to the code it was collected from (bench.py reports `traffic` only when it matches)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(SOURCES + [x for x in HEADERS if not os.path.isabs(x)]):
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode())
-            h.update(fh.read())
+        with open(os.path.join(CSRC, f), "r", errors="replace") as fh:
+            text = fh.read()
+        # comments and layout do not change the kernels: hash the code only
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        text = " ".join(text.split())
+        h.update(f.encode())
+        h.update(text.encode())
     return h.hexdigest()[:16]
 
 
