@@ -30,7 +30,7 @@ def prof(name, extra, cmd):
 bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block"]
 db = prof("stats", ["--stats"], bench + ["--steps", "2", "--warmup", "1"])
 with open(os.path.join(out, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game --no-fp32-compare\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game --no-fp32-compare --no-ten-block\n")
     f.write(subprocess.run([sys.executable, summ, "stats", db], capture_output=True, text=True).stdout)
 
 db1 = prof("single", ["--stats"], ["python", os.path.join(REPO, "tools", "time_single_game.py")])
@@ -44,7 +44,7 @@ sets = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
 vals = {}
 with open(os.path.join(out, tag + "_pmc.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 1 --warmup 0 --sims 20 "
-            "--no-cpu-baseline --no-single-game --no-fp32-compare (one pass per counter set)\n"
+            "--no-cpu-baseline --no-single-game --no-fp32-compare --no-ten-block (one pass per counter set)\n"
             "# FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE under-counts wide coalesced reads "
             "by 2x (MI355X_MICROARCH.md, HBM section)\n")
     for name, ctrs in sets.items():
