@@ -319,3 +319,53 @@ def test_fused_search_on_bit_planes_equals_stepwise_on_float_planes(B, G, S, nb,
     e1.close()
     e2.close()
     net.close()
+
+
+@pytest.mark.parametrize("mode,planes", [(4, 64), (2, 64), (3, 64), (5, 128)])
+def test_fused_search_packs_active_games_only(mode, planes):
+    """ao_search runs the network on the ACTIVE games only (rows packed to the front of the batch). With a kernel family
+    whose per-board result does not depend on the batch (modes 2 / 3 / 4; mode 5 with every move on the per-layer
+    kernel) the packed search must equal the stepwise protocol that evaluates all G slots, bit for bit, under
+    changing active masks -- and inactive games must stay untouched."""
+    import torch
+    from alpha_omok_amd.engine import Engine
+    from gpu_helpers import HostEvalRunner
+    B, S, G = 9, 20, 70
+    net = _native(2, 5, planes, B, 21)
+    net.set_mode(mode)
+    seeds = np.arange(900, 900 + G, dtype=np.uint32)
+    e1 = Engine(B, S, 5, games=G, noise=True)
+    e2 = Engine(B, S, 5, games=G, noise=True)
+    e1.seed_all(seeds)
+    e2.seed_all(seeds)
+    run = HostEvalRunner(e2)
+    rs = np.random.RandomState(3)
+    for t in range(4):
+        active = np.ones(G, np.uint8) if t == 0 else (rs.rand(G) < (0.6, 0.25, 0.05)[t - 1]).astype(np.uint8)
+        if t == 3:
+            active[:] = 0
+            active[[7, 41]] = 1
+        tau = np.ones(G, np.int8)
+        before = [e1.get_moves(g) for g in range(G)]
+        pi1, vis1, pol1 = e1.search(net, tau=tau, active=active)
+        e2.begin_move(active)
+        while e2.sims_left() > 0:
+            e2.collect_leaves(run.planes.data_ptr())
+            e2.sync()
+            p, v = net(run.planes)
+            torch.cuda.synchronize()
+            e2.apply_evals(p.data_ptr(), v.data_ptr())
+        pi2, vis2, pol2 = e2.end_move(tau)
+        on = active.astype(bool)
+        np.testing.assert_array_equal(vis1[on], vis2[on])
+        np.testing.assert_array_equal(pol1[on], pol2[on])
+        np.testing.assert_array_equal(pi1[on], pi2[on])
+        a1, w1 = e1.play()
+        a2, w2 = e2.play()
+        np.testing.assert_array_equal(a1, a2)
+        assert (a1[~on] == -1).all()
+        for g in range(G):
+            assert len(e1.get_moves(g)) == len(before[g]) + int(active[g])
+    e1.close()
+    e2.close()
+    net.close()
