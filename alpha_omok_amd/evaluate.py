@@ -92,20 +92,81 @@ def evaluate(player, enemy, board_size, n_match=12, player_elo=1500.0, enemy_elo
     return result, (player_elo, enemy_elo)
 
 
+class _ZeroSide:
+    """One network's side of evaluate_batched: a G-game engine + evaluator; searches the masked matches at their ids."""
+
+    def __init__(self, model, sims, board_size, inplanes, G, device):
+        from .engine import Engine
+        from .evaluator import Evaluator
+        self.eng = Engine(board_size, sims, inplanes, games=G, noise=False, device=device)
+        self.ev, self.model = Evaluator(device), model
+        self.tau0 = np.zeros(G, np.int8)
+
+    def seed(self, i, s):
+        self.eng.seed(i, s)
+
+    def get_rng_state(self, i):
+        return self.eng.get_rng_state(i)
+
+    def set_rng_state(self, i, mt, pos, hg, gs):
+        self.eng.set_rng_state(i, mt, pos, hg, gs)
+
+    def search(self, ids, mask):
+        self.eng.set_roots(ids, mask)
+        pi, _, _ = self.ev.search(self.eng, self.model, self.tau0, active=mask)
+        return pi
+
+    def close(self):
+        self.eng.close()
+
+
+class _RolloutSide:
+    """A PUCTAgent / UCTAgent side ('puct' / 'uct', agents.py:263-614): every get_pi is a fresh search, one kernel for
+    all masked matches."""
+
+    def __init__(self, kind, sims, board_size, G, device):
+        from .rollout import PUCT, UCT, RolloutEngine
+        self.eng = RolloutEngine(board_size, sims, PUCT if kind == 'puct' else UCT, games=G, device=device)
+
+    def seed(self, i, s):
+        self.eng.seed(i, s)
+
+    def get_rng_state(self, i):
+        return self.eng.get_rng_state(i)
+
+    def set_rng_state(self, i, mt, pos, hg, gs):
+        self.eng.set_rng_state(i, mt, pos, hg, gs)
+
+    def search(self, ids, mask):
+        pi, _, _ = self.eng.search(ids, active=mask)
+        return pi
+
+    def close(self):
+        self.eng.close()
+
+
 def evaluate_batched(player_model, enemy_model, board_size, n_mcts_player, n_mcts_enemy=None, inplanes=5, n_match=12,
-                     player_elo=1500.0, enemy_elo=1500.0, seed=0, device=0, max_plies=None):
+                     player_elo=1500.0, enemy_elo=1500.0, seed=0, device=0, max_plies=None, monitor_model=None,
+                     n_mcts_monitor=None):
     """All n_match games at once (colours swapped every game, eval_main.py:213-333). `*_model`: whatever
-    ZeroAgent.model accepts (a PVNet-shaped module runs on the native forward). Returns (result tally,
+    ZeroAgent.model accepts (a PVNet-shaped module runs on the native forward), or 'puct' / 'uct' for the rollout
+    agents (eval_main.py:68-73,106-111). With a rollout PLAYER and a `monitor_model`, the monitor ZeroAgent searches
+    the same roots right after the player as Evaluator.get_action does (eval_main.py:141-144). Returns (result tally,
     (player_elo, enemy_elo), [(win_index, moves) per match]); the ELO updates are applied in match order."""
-    from .engine import Engine
-    from .evaluator import Evaluator
     n_mcts_enemy = n_mcts_player if n_mcts_enemy is None else n_mcts_enemy
     G = n_match
     win_mark = 3 if board_size == 3 else 5
-    sides = []
-    for model, sims in ((player_model, n_mcts_player), (enemy_model, n_mcts_enemy)):
-        eng = Engine(board_size, sims, inplanes, games=G, noise=False, device=device)
-        sides.append((eng, Evaluator(device), model))
+
+    def make(model, sims):
+        if isinstance(model, str):
+            return _RolloutSide(model, sims, board_size, G, device)
+        return _ZeroSide(model, sims, board_size, inplanes, G, device)
+
+    sides = [make(player_model, n_mcts_player), make(enemy_model, n_mcts_enemy)]
+    monitor = None
+    if monitor_model is not None and isinstance(player_model, str):
+        monitor = _ZeroSide(monitor_model, n_mcts_monitor or n_mcts_enemy, board_size, inplanes, G, device)
+        sides.append(monitor)                                       # index 2: searches right after side 0
     enemy_turn = np.array([1 - (i % 2) for i in range(G)])          # match 0: the player is black
     ids = [(0,) for _ in range(G)]
     wins = np.zeros(G, np.int64)
@@ -113,8 +174,15 @@ def evaluate_batched(player_model, enemy_model, board_size, n_mcts_player, n_mct
     # one stream per match, handed from the side that just searched to the side that searches next
     holder = np.where(enemy_turn == 0, 1, 0)                        # the side that moves first holds the stream
     for i in range(G):
-        sides[holder[i]][0].seed(i, (seed + i) & 0xFFFFFFFF)
-    tau0 = np.zeros(G, np.int8)
+        sides[holder[i]].seed(i, (seed + i) & 0xFFFFFFFF)
+
+    def take_stream(side, mask):
+        for i in np.nonzero(mask)[0]:
+            if holder[i] != side:                                    # another side drew last: take the stream over
+                mt, pos, hg, gs = sides[holder[i]].get_rng_state(int(i))
+                sides[side].set_rng_state(int(i), mt, pos, hg, gs)
+                holder[i] = side
+
     ply = 0
     while running.any():
         turn = ply % 2
@@ -122,15 +190,12 @@ def evaluate_batched(player_model, enemy_model, board_size, n_mcts_player, n_mct
             mask = running & ((enemy_turn == turn) == (side == 1))
             if not mask.any():
                 continue
-            eng, ev, model = sides[side]
-            for i in np.nonzero(mask)[0]:
-                if holder[i] != side:                                # the opponent drew last: take the stream over
-                    mt, pos, hg, gs = sides[holder[i]][0].get_rng_state(int(i))
-                    eng.set_rng_state(int(i), mt, pos, hg, gs)
-                    holder[i] = side
             m8 = mask.astype(np.uint8)
-            eng.set_roots(ids, m8)
-            pi, _, _ = ev.search(eng, model, tau0, active=m8)
+            take_stream(side, mask)
+            pi = sides[side].search(ids, m8)
+            if side == 0 and monitor is not None:
+                take_stream(2, mask)
+                monitor.search(ids, m8)
             for i in np.nonzero(mask)[0]:
                 a = int(np.argmax(pi[i]))                            # argmax_onehot of a one-hot: no draw (utils.py:198-205)
                 ids[i] = ids[i] + (a,)
@@ -138,8 +203,8 @@ def evaluate_batched(player_model, enemy_model, board_size, n_mcts_player, n_mct
                 if wins[i] != 0 or (max_plies and len(ids[i]) - 1 >= max_plies):
                     running[i] = False
         ply += 1
-    for eng, _, _ in sides:
-        eng.close()
+    for sd in sides:
+        sd.close()
     result = {'Player': 0, 'Enemy': 0, 'Draw': 0}
     games = []
     for i in range(G):

@@ -275,6 +275,35 @@ def test_evaluate_batched_equals_sequential_matches(oracle):
         assert sum(res_b.values()) == n_match
 
 
+def test_evaluate_batched_with_rollout_player_and_monitor(oracle):
+    """evaluate_batched with a PUCT / UCT player ('puct' / 'uct'), a ZeroAgent enemy and the monitor: every match
+    equals `np.random.seed(seed + i); play_match(rollout agent, ZeroAgent, monitor=...)`; match 0 of each kind with
+    gv13's seeds reproduces the reference's own mixed match."""
+    from alpha_omok_amd import agents, evaluate
+    agents.PRINT_MCTS = False
+    g = load_golden("gv13_eval_head_to_head")
+    for mi in range(int(g["nmixed"])):
+        B, mode, SP, SE, SM, me, mm, seed, enemy_turn = g["m%d_cfg" % mi].tolist()
+        kind = 'puct' if mode == 0 else 'uct'
+        n_match = 4
+        res, elos, games = evaluate.evaluate_batched(kind, StubModel(oracle, me), B, SP, SE, n_match=n_match, seed=seed,
+                                                     monitor_model=StubModel(oracle, mm), n_mcts_monitor=SM)
+        player = (agents.PUCTAgent if mode == 0 else agents.UCTAgent)(B, SP)
+        enemy = agents.ZeroAgent(B, SE, 5, noise=False)
+        enemy.model = StubModel(oracle, me)
+        monitor = agents.ZeroAgent(B, SM, 5, noise=False)
+        monitor.model = StubModel(oracle, mm)
+        et = 1
+        for i in range(n_match):
+            np.random.seed(seed + i)
+            win, moves = evaluate.play_match(player, enemy, B, et, monitor=monitor)
+            assert moves == games[i][1] and win == games[i][0], (kind, i)
+            et ^= 1
+        if enemy_turn == 1:        # gv13's match has the colours of batched match 0
+            assert games[0][1] == g["m%d_moves" % mi].tolist() and games[0][0] == int(g["m%d_win" % mi])
+        assert sum(res.values()) == n_match
+
+
 def test_run_loop_iterations_save_and_train(tmp_path):
     """main.run = the reference's __main__ loop (main.py:377-414): iteration 0 only plays, later
     iterations play one game and train on it; checkpoints appear when n_iter % save_every == 0 and
