@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1x"
 out = os.path.join(REPO, "gpurun_out", "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare",
+cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block",
        "--steps", "1", "--warmup", "0", "--sims", "20"]
 GROUPS = {
     "waves": ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"],
@@ -25,7 +25,7 @@ GROUPS = {
 }
 with open(os.path.join(out, tag + "_pmc_deep.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 1 --warmup 0 --sims 20 --no-cpu-baseline "
-            "--no-single-game --no-fp32-compare   (one pass per group; average per dispatch, summed over instances)\n")
+            "--no-single-game --no-fp32-compare --no-ten-block   (one pass per group; average per dispatch, summed over instances)\n")
     for name, ctrs in GROUPS.items():
         d = os.path.join(out, "raw_deep_" + name)
         subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["-d", d, "-o", name, "--"] + cmd, cwd="/tmp", env=env,
