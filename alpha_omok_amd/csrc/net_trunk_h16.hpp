@@ -71,7 +71,9 @@ __device__ unsigned long long ao_prof[8 * 12];
 // Knock-out switches for timing experiments (-DAO_KO=n together with -DAO_PROF; RESULTS ARE WRONG for n != 0, the
 // default build has AO_KO = 0 and every condition below folds away): 1 weights loaded for the first slabs only,
 // 2 LDS operand fragments read once per slab, 3 no staging of input rows, 4 no row epilogues (residual loads +
-// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint, 8 no heads. Measured: profiles/r1j_trunk16h_phase_timing.txt
+// stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint, 8 no heads, 10 the low halves move half
+// their bytes (staged by lanes 0-31 only, stored / re-read as 4 bytes per lane: the traffic of a 3-byte activation format
+// without its conversion work). Measured: profiles/r1j_trunk16h_phase_timing.txt, r3a_trunk16h_bytes_ko.txt
 #ifndef AO_KO
 #define AO_KO 0
 #endif
@@ -201,6 +203,10 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                     const int i = i0 + k < BW ? i0 + k : BW - 1;
                     const int ob = (((py(yo) * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
                     rh[k] = buf_ld_h4(rs_dst, out_voff, ob);
+                    if (AO_KO == 10) {
+                        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rs_dst, out_voff >> 1, ob + 1024, AO_AUX_RES);
+                        rl[k] = __builtin_bit_cast(half4, u32x2{u, u});
+                    } else
                     rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
                 }
             }
@@ -227,6 +233,8 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                     hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
                 }
                 buf_st_h4(hh, rs_dst, out_voff, ob);
+                if (AO_KO == 10) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32x2, hl)[0], rs_dst, out_voff >> 1, ob + 1024, AO_AUX_ST);
+                else
                 buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
             }
         }
@@ -248,7 +256,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
 #pragma unroll
         for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
             const int f = tile + NT * k;
-            if (f < NFR)
+            if (f < NFR && !(AO_KO == 10 && (f & 1) && lane >= 32))
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
                                                          (py(0) * NFR + f) * 1024, 0, AO_AUX_STAGE);
         }
@@ -284,7 +292,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                     const int f = tile + NT * (c * ((NFR / NT + NCI) / NCI) + k);
                     if (f < NFR) {
                         if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
-                        else
+                        else if (!(AO_KO == 10 && (f & 1) && lane >= 32))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
                                                                      16, lane16, (py(yn) * NFR + f) * 1024, 0, AO_AUX_STAGE);
                     }
