@@ -76,6 +76,7 @@ SYMBOLS = {
     "ao_net_status": (C.c_int, [_vp, _vp, _i32p, C.c_int]),
     "ao_net_conv_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_net_dominant_kernel": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _f64p]),
+    "ao_net_plan_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _f64p]),
     "ao_replay_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _P(_vp)]),
     "ao_replay_destroy": (None, [_vp]),
     "ao_replay_last_error": (C.c_char_p, [_vp]),

@@ -69,6 +69,7 @@ struct ao_net {
     int ring_head = 0, ring_count = 0;
     double ms_total = 0.0;
     int64_t launches = 0;
+    int last_in_kind = 1;                          // input of the most recent forward: 1 fp32 plane batch, 2 the engine's bit planes
 
     int fail(const std::string& m) { err = m; return 1; }
 };
@@ -292,6 +293,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     net_plan(n, boards, &group, &nchq, nullptr);
     const int mode = pick_mode(n, boards, &nch);
     if (in_kind == 2 && !(mode == 5 && n->C <= 8)) return n->fail("bit planes handed to a kernel that takes the fp32 batch");
+    n->last_in_kind = in_kind == 2 ? 2 : 1;
     const int groups = (boards + group - 1) / group;
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
@@ -855,41 +857,77 @@ int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launche
     return 0;
 }
 
-int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, double* flop_per_launch) {
+// Name (as rocprofv3 prints it, template arguments included) and algorithmic FLOPs per launch of the kernel that
+// carries the conv stack for a batch of `boards` positions; in_kind 2 = the engine's bit planes (ao_search), 1 = the
+// fp32 plane batch (ao_net_forward). Pure host logic: no device is touched.
+static void dominant_name(const ao_net* n, int boards, int in_kind, std::string* nm_out, double* f_out) {
     int group = 32, nchq = 0;
     ao::net_plan(n, boards, &group, &nchq, nullptr);
     const int padded = (boards + group - 1) / group * group;
     const double conv = 2.0 * n->A * 9.0 * n->planes * n->planes * padded;   // one planes->planes 3x3 conv
     const double conv1 = 2.0 * n->A * 9.0 * n->C * n->planes * padded;
+    const int mode = ao::pick_mode_public(n, boards);
+    const std::string bw = std::to_string(n->B);
     std::string nm;
     double f;
     if (group == 1) {
-        nm = "k_conv_cells<" + std::to_string(n->B) + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
+        nm = "k_conv_cells<" + bw + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
         f = conv;
- } else if (group == 16 && ao::pick_mode_public(n, boards) == 4) {
-        nm = "k_layer16<" + std::to_string(n->B) + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
+    } else if (group == 16 && mode == 4) {
+        nm = "k_layer16<" + bw + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
-    } else if (group == 16 && ao::pick_mode_public(n, boards) == 5 && !(n->B <= 9 && (boards + 15) / 16 >= 192)) {
-        nm = "k_layer16h<" + std::to_string(n->B) + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
+    } else if (group == 16 && mode == 5 && !(n->B <= 9 && (boards + 15) / 16 >= 192)) {
+        nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
              "16-board groups x row chunks x column tiles)";
         f = conv;
-    } else if (group == 16 && ao::pick_mode_public(n, boards) == 5) {
-        nm = "k_trunk16h<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
-             " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), one resident launch)";
+    } else if (group == 16 && mode == 5) {
+        nm = std::string(in_kind == 2 ? "k_trunk16hb<" : "k_trunk16h<") + bw + ", 4> (conv1 + " + std::to_string(2 * n->nb) +
+             " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate) + heads, one resident launch)";
         f = conv1 + 2.0 * n->nb * conv;
     } else if (group == 16) {
-        nm = "k_trunk16<" + std::to_string(n->B) + "> (conv1 + " + std::to_string(2 * n->nb) +
-             " 3x3 convs, one launch, fp32 MFMA 16x16x4)";
+        nm = "k_trunk16<" + bw + "> (conv1 + " + std::to_string(2 * n->nb) + " 3x3 convs, one launch, fp32 MFMA 16x16x4)";
         f = conv1 + 2.0 * n->nb * conv;
     } else {
-        nm = "k_conv3x3<" + std::to_string(n->B) + "> (one 3x3 " + std::to_string(n->planes) + "->" +
-             std::to_string(n->planes) + " conv, fp32 MFMA 32x32x2)";
+        nm = "k_conv3x3<" + bw + "> (one 3x3 " + std::to_string(n->planes) + "->" + std::to_string(n->planes) +
+             " conv, fp32 MFMA 32x32x2)";
         f = conv;
     }
+    *nm_out = nm;
+    *f_out = f;
+}
+
+static void copy_name(const std::string& nm, char* name, int name_cap) {
     if (name && name_cap > 0) {
         std::strncpy(name, nm.c_str(), static_cast<size_t>(name_cap) - 1);
         name[name_cap - 1] = 0;
     }
+}
+
+int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, double* flop_per_launch) {
+    std::string nm;
+    double f = 0.0;
+    dominant_name(n, boards, n->last_in_kind, &nm, &f);
+    copy_name(nm, name, name_cap);
+    if (flop_per_launch) *flop_per_launch = f;
+    return 0;
+}
+
+int ao_net_plan_kernel(int n_block, int inplanes, int planes, int board, int trunk_mode, int boards, int in_kind,
+                       char* name, int name_cap, double* flop_per_launch) {
+    if (n_block < 0 || inplanes < 1 || planes < 32 || planes % 32 || board < 3 || board > ao::kMaxBoard || boards < 1 ||
+        trunk_mode < 0 || trunk_mode > 5)
+        return 1;
+    ao_net n;   // never finalized, owns nothing: the planning fields of ao_net_create without a device
+    n.nb = n_block; n.C = inplanes; n.planes = planes; n.B = board; n.A = board * board;
+    n.nchq32 = (((inplanes + 3) / 4) + 1) & ~1;
+    n.nchq16 = (((inplanes + 3) / 4) + 7) & ~7;
+    n.nchq1 = (((inplanes + 3) / 4) + 3) & ~3;
+    n.CQ = planes / 4;
+    n.mode = trunk_mode;
+    std::string nm;
+    double f = 0.0;
+    dominant_name(&n, boards, in_kind, &nm, &f);
+    copy_name(nm, name, name_cap);
     if (flop_per_launch) *flop_per_launch = f;
     return 0;
 }

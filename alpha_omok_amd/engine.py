@@ -19,6 +19,19 @@ def _ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
 
 
+def plan_kernel(n_block, inplanes, planes, board_size, boards, in_kind=2, trunk_mode=0):
+    """(kernel name as rocprofv3 prints it + description, algorithmic FLOPs per launch) of the kernel that would
+    carry the conv stack for `boards` positions -- planning logic only, needs no GPU (ao_net_plan_kernel).
+    in_kind 2: the engine's bit planes (what ao_search feeds), 1: the fp32 plane batch (ao_net_forward)."""
+    L = _lib.load()
+    buf = C.create_string_buffer(256)
+    f = C.c_double(0)
+    if L.ao_net_plan_kernel(int(n_block), int(inplanes), int(planes), int(board_size), int(trunk_mode), int(boards),
+                            int(in_kind), buf, 256, C.byref(f)):
+        raise EngineError("ao_net_plan_kernel: bad network shape")
+    return buf.value.decode(), f.value
+
+
 class Net:
     """model.PVNet(n_block, inplanes, planes, board_size) in eval() mode, on the MI355X."""
 

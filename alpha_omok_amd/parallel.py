@@ -18,6 +18,14 @@ def world():
     return 0, 1
 
 
+def _collectives_on():
+    """Collectives run whenever a process group exists -- also a group of ONE rank (the RCCL smoke test on a 1-GPU
+    box, tests/test_gpu_multirank.py): the all-reduce of a single rank is the identity, but it loads librccl and
+    runs on the device buffers exactly as at 8 ranks. Without a process group every function below is a no-op."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment; no-op for a single process."""
     import torch.distributed as dist
@@ -44,8 +52,7 @@ def shard_games(n_games, rank, world_size):
 def broadcast_parameters(module, src=0):
     """Identical weights and BN buffers on every rank (one flat buffer, one broadcast)."""
     import torch.distributed as dist
-    rank, n = world()
-    if n == 1:
+    if not _collectives_on():
         return
     tensors = [t for t in module.state_dict().values() if t.is_floating_point()]
     flat = torch.cat([t.detach().reshape(-1) for t in tensors])
@@ -74,8 +81,7 @@ def agree(value, op="max", device=None):
     """One integer every rank ends up with: max / min / sum of the ranks' local values. Used wherever a
     later loop issues collectives, so that every rank runs the same number of them."""
     import torch.distributed as dist
-    rank, n = world()
-    if n == 1:
+    if not _collectives_on():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device or "cpu")
     if dist.get_backend() == "nccl" and not t.is_cuda:
@@ -92,9 +98,8 @@ def allreduce_gradients(module, contributes=True):
     zeros. The last element of the buffer counts the contributors, so the divisor travels in the same
     message. Returns (elements reduced, contributing ranks); with one process it is a no-op."""
     import torch.distributed as dist
-    rank, n = world()
     params = [p for p in module.parameters() if p.requires_grad]
-    if n == 1:
+    if not _collectives_on():
         return sum(p.numel() for p in params), 1 if contributes else 0
     dev = params[0].device
     if contributes:
@@ -128,8 +133,7 @@ def average_buffers(module, contributes=True):
     (one flattened all-reduce) and num_batches_tracked becomes the maximum, which leaves the state_dict
     bit-identical on every rank (the gradients already were)."""
     import torch.distributed as dist
-    rank, n = world()
-    if n == 1:
+    if not _collectives_on():
         return
     fl = [b for b in module.buffers() if b.is_floating_point()]
     it = [b for b in module.buffers() if not b.is_floating_point()]

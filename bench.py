@@ -188,6 +188,41 @@ def cpu_all_cores(board, sims, n_block, planes, state_dict, budget_s):
                        % (ok, min(sims, 40), budget_s, sims))
 
 
+def kernel_key(name):
+    """'k_trunk16hb<9, 4> (conv1 + ...)' / 'void ao::k_trunk16hb<9, 4>(ao::TrunkHArgs)' -> ('k_trunk16hb', '9'):
+    kernel base name + board width (the first template argument), the part every naming of a launch agrees on."""
+    n = name.replace("void ", "").replace("ao::", "").strip()
+    base = n.split("<")[0].split("(")[0].strip()
+    first = n.split("<")[1].split(",")[0].split(">")[0].strip() if "<" in n else ""
+    return base, first
+
+
+def match_traffic(tj, kname, csrc_sha, workload_is_default):
+    """The rule that lets a committed rocprofv3 PMC summary (profiles/r*_traffic.json) speak for this run: collected
+    from the same kernel sources (hash of csrc/), on the default workload, for the kernel that runs now. Returns
+    (dominant-kernel HBM bytes per launch or None, tree-kernel record or None, reason when rejected)."""
+    same_code = tj.get("csrc_sha16") == csrc_sha
+    if not same_code:
+        return None, None, "collected from other kernel sources (csrc hash %s, now %s)" % (tj.get("csrc_sha16"), csrc_sha)
+    if not workload_is_default:
+        return None, None, "collected on the default workload (4096 games, 9x9, 4 blocks), this run differs"
+    tree = tj.get("tree")
+    if kernel_key(tj.get("kernel", "")) != kernel_key(kname):
+        return None, tree, "collected for kernel %s, this run's dominant kernel is %s" % (tj.get("kernel"), kname.split(" (")[0])
+    return tj.get("hbm_bytes_per_launch"), tree, None
+
+
+def newest_traffic_profile():
+    import glob
+    import re
+    files = glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json"))
+
+    def key(p):  # r<round><letter...>: newest round, then newest letter
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(p))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    return sorted(files, key=key)[-1] if files else None
+
+
 class TrainStep:
     """BASELINE configs[3]'s training step beside the self-play: one mini-batch of 32 from the rank-local replay
     shard (device-resident ring, filled before the timed region by real self-play games of this engine at a small
@@ -258,6 +293,27 @@ class TrainStep:
         return r
 
 
+def launch_ranks(n):
+    """Re-run this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1). Fails loudly -- exit code
+    2, nothing printed on stdout -- when fewer than n GPUs are visible, instead of reporting a 1-GPU number under an
+    N-GPU label."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get("AO_BENCH_SHARE_GPU"):
+        print("bench.py: --gpus %d requested but %d GPU(s) are visible on this node; refusing to report an %d-GPU number "
+              "(AO_BENCH_SHARE_GPU=1 AO_BENCH_BACKEND=gloo runs the ranks on shared devices for a functional check)"
+              % (n, have, n), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,7 +348,14 @@ def main():
         cpu_worker(args.board, args.sims, args.blocks, args.planes, args.cpu_worker, args.cpu_budget)
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, RCCL), exactly
+        # as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` would
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s): reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -395,21 +458,17 @@ def main():
         traffic = None
         traffic_src = None
         tree_traffic = None
+        traffic_why = "no profile"
         from alpha_omok_amd.build import source_hash
         csrc_sha = source_hash()
         try:
-            import glob
-            traffic_src = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")))[-1]  # newest round
+            traffic_src = newest_traffic_profile()
             with open(traffic_src) as f:
                 tj = json.load(f)
-            same_code = tj.get("csrc_sha16") == csrc_sha
-            same_load = (G == 4096 and B == 9 and args.blocks == 4 and args.planes == 128)
-            if tj["kernel"].split("<")[0] == kname.split("<")[0] and same_load and same_code:
-                traffic = tj["hbm_bytes_per_launch"]
-            if same_load and same_code and tj.get("tree"):
-                tree_traffic = tj["tree"]
-        except Exception:
-            traffic = None
+            same_load = (G == 4096 and B == 9 and args.blocks == 4 and args.planes == 128 and S == 400)
+            traffic, tree_traffic, traffic_why = match_traffic(tj, kname, csrc_sha, same_load)
+        except Exception as e:
+            traffic, traffic_why = None, "profile unreadable: %r" % (e,)
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
         split16 = kname.startswith("k_trunk16h") or kname.startswith("k_layer16h")
         peak = PEAK_F16_MFMA_TFLOPS if split16 else PEAK_F32_MFMA_TFLOPS
@@ -463,8 +522,7 @@ def main():
                 "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % (
-                    (os.path.relpath(traffic_src, REPO) + ("" if traffic is not None else
-                                                            ": NOT used, collected from other kernel sources or another workload"))
+                    (os.path.relpath(traffic_src, REPO) + ("" if traffic is not None else ": NOT used, " + str(traffic_why)))
                     if traffic_src else "no profile"),
                 "csrc_sha16": csrc_sha,
                 "flop_per_launch": f_launch,

@@ -180,6 +180,12 @@ int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launch
 /* name and algorithmic FLOPs per launch (2*MAC, zero padding counted) of the kernel the timing
  * refers to, for a batch of `boards` positions. */
 int  ao_net_dominant_kernel(ao_net *n, int boards, char *name, int name_cap, double *flop_per_launch);
+/* the same answer without a network object or a device (pure planning logic): which kernel would carry the conv
+ * stack of a PVNet(n_block, inplanes, planes, board) (model.py:76-85) for `boards` positions, trunk_mode as in
+ * ao_net_set_mode, in_kind 1 = fp32 plane batch (ao_net_forward), 2 = the engine's bit planes (ao_search).
+ * bench.py and tests/test_host_side.py use it to tie a committed rocprofv3 summary to the kernel that runs. */
+int  ao_net_plan_kernel(int n_block, int inplanes, int planes, int board, int trunk_mode, int boards, int in_kind,
+                        char *name, int name_cap, double *flop_per_launch);
 
 /* ---- replay memory ---- replaces rep_memory = deque(maxlen=MEMORY_SIZE) (main.py:55), its
  * rep_memory.extend(utils.augment_dataset(cur_memory, board_size)) (main.py:229-231,

@@ -1,0 +1,64 @@
+"""CPU: the measurement plumbing of bench.py (round-2 review, item 1).
+
+* the committed rocprofv3 PMC summary bench.py's `roofline.traffic` quotes must be accepted by bench.py's own
+  matching rule for the kernel that runs the default workload and for the CURRENT kernel sources -- a stale or
+  mis-named profile makes the driver's record say `traffic: null` (that happened in round 2);
+* `python bench.py --gpus N` without a launcher starts the ranks itself and refuses -- exit code 2, nothing on
+  stdout -- when fewer than N GPUs are visible, instead of printing a 1-GPU line under an N-GPU label."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+
+def test_newest_traffic_profile_matches_the_kernel_that_runs():
+    import bench
+    from alpha_omok_amd.build import source_hash
+    from alpha_omok_amd.engine import plan_kernel
+    path = bench.newest_traffic_profile()
+    assert path is not None, "no profiles/r*_traffic.json committed"
+    with open(path) as f:
+        tj = json.load(f)
+    # the kernel ao_search launches for BASELINE configs[2] (4096 boards, bit planes), by the library's own planning
+    kname, flop = plan_kernel(4, 5, 128, 9, 4096, in_kind=2)
+    assert flop == pytest.approx(2.0 * 81 * 9 * (5 * 128 + 8 * 128 * 128) * 4096)
+    assert bench.kernel_key(tj["kernel"]) == bench.kernel_key(kname), (
+        "%s was collected for %s, the default workload runs %s" % (os.path.basename(path), tj["kernel"], kname.split(" (")[0]))
+    if os.environ.get("AO_ALLOW_STALE_PROFILE"):   # developer switch while kernels are being edited between GPU profile runs
+        return
+    traffic, tree, why = bench.match_traffic(tj, kname, source_hash(), True)
+    assert traffic is not None and traffic > 1e9, "bench.py would report roofline.traffic = null: %s" % why
+    assert tree and tree.get("hbm_bytes_per_launch"), "no tree-kernel traffic in %s" % os.path.basename(path)
+
+
+def test_kernel_key_normalises_rocprof_and_library_names():
+    import bench
+    assert bench.kernel_key("void ao::k_trunk16hb<9, 4>(ao::TrunkHArgs)") == ("k_trunk16hb", "9")
+    assert bench.kernel_key("k_trunk16hb<9, 4> (conv1 + 8 3x3 convs ...)") == ("k_trunk16hb", "9")
+    assert bench.kernel_key("k_trunk16h<9, 4>") != bench.kernel_key("k_trunk16hb<9, 4>")
+    assert bench.kernel_key("k_layer16h<15> (one 3x3 conv per launch ...)") == bench.kernel_key("void ao::k_layer16h<15, 4, 4, 0>(ao::LayerHArgs)")
+
+
+def test_plan_kernel_follows_batch_size_and_input_kind():
+    from alpha_omok_amd.engine import plan_kernel
+    assert plan_kernel(4, 5, 128, 9, 4096, in_kind=1)[0].startswith("k_trunk16h<9, 4>")
+    assert plan_kernel(4, 5, 128, 9, 1, in_kind=1)[0].startswith("k_conv_cells<9>")
+    assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2)[0].startswith("k_layer16h<15>")
+    assert plan_kernel(4, 5, 64, 9, 4096, in_kind=1)[0].startswith("k_trunk16<9>")
+    assert plan_kernel(4, 5, 128, 9, 4096, in_kind=1, trunk_mode=2)[0].startswith("k_trunk16<9>")
+
+
+def test_bench_gpus_n_refuses_without_n_devices():
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AO_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert r.stdout.strip() == "", "a bench line was printed although the requested GPUs are not there"
+    assert "--gpus 2" in r.stderr and "visible" in r.stderr

@@ -116,3 +116,55 @@ def test_two_ranks_run_the_training_loop_without_deadlock(tmp_path):
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     models = [f for f in os.listdir(ck) if f.endswith("_step_model.pickle")]
     assert len(models) == 2                               # n_iter 0 and 2, written once (rank 0)
+
+
+def _rccl_worker(rank, world, port, out):
+    """ONE rank, backend "nccl" (= RCCL on ROCm) on cuda:0: every collective of parallel.py runs on device buffers."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from alpha_omok_amd import parallel
+    from alpha_omok_amd.pvnet import PVNet
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and parallel.world() == (0, 1) and parallel._collectives_on()
+    torch.manual_seed(5)
+    net = PVNet(2, 5, 32, 9).cuda()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    parallel.broadcast_parameters(net)                       # ncclBroadcast of one flat device buffer
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    net.train()
+    x = (torch.rand(8, 5, 9, 9, device="cuda") < 0.3).float()
+    p, v = net(x)
+    (p.log().mean() + v.pow(2).mean()).backward()
+    g0 = [q.grad.clone() for q in net.parameters()]
+    numel, contributors = parallel.allreduce_gradients(net, contributes=True)   # ncclAllReduce(sum) + contributor count
+    assert contributors == 1 and numel == sum(q.numel() for q in net.parameters())
+    for q, g in zip(net.parameters(), g0):
+        assert torch.equal(q.grad, g), "a one-rank all-reduce must leave the gradient unchanged"
+    b0 = [b.clone() for b in net.buffers()]
+    parallel.average_buffers(net, contributes=True)
+    for b, w in zip(net.buffers(), b0):
+        assert torch.equal(b, w)
+    assert parallel.agree(17, "sum", torch.device("cuda", 0)) == 17 and parallel.agree(3, "max") == 3
+    # a rank that does not contribute adds zeros and the count says so
+    _, c0 = parallel.allreduce_gradients(net, contributes=False)
+    assert c0 == 0
+    maps = open("/proc/self/maps").read()
+    torch.save(dict(rccl_mapped="librccl" in maps, backend=dist.get_backend(), numel=numel), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_every_collective_on_device_buffers(tmp_path):
+    """RCCL itself (librccl.so, the `nccl` backend) on this 1-GPU box: a process group of ONE rank drives
+    broadcast_parameters / allreduce_gradients / average_buffers / agree on cuda:0 buffers -- the branches the gloo
+    tests never enter. At world 8 the same code runs over xGMI."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rccl.pt")
+    mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["backend"] == "nccl" and r["rccl_mapped"], "librccl is not mapped: the nccl backend did not load RCCL"
