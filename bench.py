@@ -109,7 +109,7 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
     ag.get_pi(root, 1)  # warm-up move (also pages torch in); not timed
     t0 = time.perf_counter()
     moves = 0
-    while time.perf_counter() - t0 < budget_s and moves < 40:
+    while time.perf_counter() - t0 < budget_s and moves < 80:
         pi, vis, pol = ag.get_pi(root, 1 if len(root) <= 6 else 0)
         a = ag.rng.choice_p(pi)
         root = root + (int(a),)
@@ -182,10 +182,64 @@ def cpu_all_cores(board, sims, n_block, planes, state_dict, budget_s):
                 ok += 1
             except Exception:
                 pass
-    return dict(value=rate, unit="move-decisions/s", processes=ok, threads_per_process=1,
+    return dict(value=rate, unit="move-decisions/s (ESTIMATED: simulations/s / %d, searched in chunks of %d simulations -- shallower "
+                                 "trees than a %d-simulation move, so an upper bound for this host)" % (sims, min(sims, 40), sims),
+                simulations_per_s=rate * sims, chunk_sims=min(sims, 40), processes=ok, threads_per_process=1,
                 sample="%d independent single-threaded processes (one per hardware thread), each searching successive "
                        "positions of its own game in chunks of %d simulations for %.0f s; simulations / %d = move decisions"
                        % (ok, min(sims, 40), budget_s, sims))
+
+
+def tictactoe_bench(device, sims=200, budget_s=3.0):
+    """BASELINE configs[0]: 3x3 tic-tac-toe, pure UCT (1_tictactoe_MCTS/mcts_vs.py:134-202), `sims` simulations per
+    move. CPU = the oracle's C restatement of that search on one host core, playing whole games; GPU = k_ttt_search
+    (one wavefront per board, a whole search per launch) for 1 board (latency) and 4096 boards (throughput)."""
+    from alpha_omok_amd import utils
+    from alpha_omok_amd.tictactoe import TttEngine
+    from oracle import oracle_py as O
+    rng = O.PyRandom()
+    rng.seed(0)
+    t0 = time.perf_counter()
+    moves = games = 0
+    while time.perf_counter() - t0 < budget_s:
+        board = np.zeros((3, 3), np.int8)
+        turn = 0
+        while True:
+            a, q, n = O.ttt_search(board, turn, sims, rng)
+            board[a // 3, a % 3] = 1 if turn == 0 else -1
+            turn ^= 1
+            moves += 1
+            if utils.check_win(board.astype(float), 3) != 0:
+                break
+        games += 1
+    cpu_dt = time.perf_counter() - t0
+    out = {"workload": "BASELINE configs[0]: 3x3 tic-tac-toe, pure UCT (mcts_vs.py), %d sims/move" % sims,
+           "cpu_port": {"value": moves / cpu_dt, "unit": "move-decisions/s", "cores": 1, "kind": "port",
+                        "sample": "%d move decisions of %d whole games, oracle C restatement, one thread, %.1f s" % (moves, games, cpu_dt)}}
+    rs = np.random.RandomState(0)
+    for G in (1, 4096):
+        eng = TttEngine(sims, games=G, device=device)
+        for g in range(G):
+            eng.seed(g, g)
+        boards = np.zeros((G, 3, 3), np.int8)
+        # a mix of opening positions: 0-2 stones already on the board
+        for g in range(G):
+            k = g % 3
+            cells = rs.permutation(9)[:k]
+            for j, c in enumerate(cells):
+                boards[g, c // 3, c % 3] = 1 if j % 2 == 0 else -1
+        turns = np.array([(g % 3) % 2 for g in range(G)], np.int32)
+        eng.search(boards, turns)
+        reps = 20 if G == 1 else 5
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            eng.search(boards, turns)
+        dt = (time.perf_counter() - t1) / reps
+        out["gpu_%d_board%s" % (G, "" if G == 1 else "s")] = {
+            "value": G / dt, "unit": "move-decisions/s", "ms_per_launch": dt * 1e3,
+            "kernel": "k_ttt_search (one wavefront per board, all %d simulations in one launch)" % sims}
+        eng.close()
+    return out
 
 
 def kernel_key(name):
@@ -324,9 +378,10 @@ def main():
     ap.add_argument("--board", type=int, default=9)
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--planes", type=int, default=128)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline sample")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU baseline sample (>= 30 move decisions on the GPU box's host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-game", action="store_true")
+    ap.add_argument("--no-tictactoe", action="store_true", help="skip BASELINE configs[0] (3x3 UCT, 200 sims): oracle on one core beside k_ttt_search")
     ap.add_argument("--trunk-mode", type=int, default=0,
                     help="0 auto, 1 layer kernels, 2 group-resident fp32-MFMA trunk, 3 per-board, 4 row-chunked, "
                          "5 group-resident split-fp16 trunk")
@@ -569,7 +624,7 @@ def main():
                 out["fp32_mfma_trunk"] = {"value": None, "error": repr(e)}
             net.set_mode(args.trunk_mode)
         if world == 1 and args.blocks != 10 and not args.no_ten_block:
-            # the reference's own default network (main.py:33 N_BLOCKS = 10) on the same workload, two steps
+            # the reference's own default network (main.py:33 N_BLOCKS = 10) on the same workload, five steps
             try:
                 torch.manual_seed(0)
                 m10 = PVNet(10, 5, args.planes, B)
@@ -578,12 +633,13 @@ def main():
                 step(False, net10)
                 fence()
                 t1 = time.perf_counter()
-                for _ in range(2):
+                n10 = 5
+                for _ in range(n10):
                     step(False, net10)
                 fence()
                 d1 = time.perf_counter() - t1
                 out["ten_block_net"] = {"workload": "same games, random-init 10-block/%d-ch PVNet (the reference's default, main.py:33)" % args.planes,
-                                        "value": 2 * G / d1, "unit": "move-decisions/s", "ms_per_step": d1 / 2 * 1e3,
+                                        "value": n10 * G / d1, "unit": "move-decisions/s", "ms_per_step": d1 / n10 * 1e3, "steps": n10,
                                         "flops_per_move_algorithmic": S * eval_flops(B, 5, args.planes, 10)}
                 net10.close()
             except Exception as e:
@@ -610,6 +666,11 @@ def main():
                 one.close()
             except Exception as e:
                 out["single_game"] = {"value": None, "error": repr(e)}
+        if world == 1 and not args.no_tictactoe:
+            try:
+                out["tictactoe"] = tictactoe_bench(local)
+            except Exception as e:
+                out["tictactoe"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(B, S, args.blocks, args.planes, sd, args.cpu_budget)
