@@ -65,6 +65,8 @@ SYMBOLS = {
     "ao_tree_nodes": (C.c_int, [_vp, C.c_int, _i64p, _i64p]),
     "ao_tree_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_trim_stats": (C.c_int, [_vp, _i64p, _i64p]),
+    "ao_node_cap": (C.c_int, [_vp, _i32p, _i32p]),
+    "ao_fp16_range_events": (C.c_int, [_vp, _i64p, _i64p]),
     "ao_search_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "ao_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(_vp)]),
     "ao_net_destroy": (None, [_vp]),
@@ -73,6 +75,7 @@ SYMBOLS = {
     "ao_net_finalize": (C.c_int, [_vp]),
     "ao_net_forward": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "ao_net_set_mode": (C.c_int, [_vp, C.c_int]),
+    "ao_net_get_mode": (C.c_int, [_vp]),
     "ao_net_status": (C.c_int, [_vp, _vp, _i32p, C.c_int]),
     "ao_net_conv_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_net_dominant_kernel": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _f64p]),

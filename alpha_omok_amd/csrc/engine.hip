@@ -68,6 +68,12 @@ struct ao_engine {
     int32_t* h_i32 = nullptr;        // pinned [4][G]
     int sims_left = 0;
     bool in_move = false, ended = false;
+    // fp16-range recovery of ao_search: the games' MT19937 states as they were before the move (device copy), the host
+    // half of the stream (legacy gauss cache), the number of recovered moves and of games searched again
+    uint32_t* d_mt_backup = nullptr; int32_t* d_pos_backup = nullptr;
+    std::vector<int32_t> has_gauss_backup; std::vector<double> gauss_backup;
+    int64_t fp16_events = 0, fp16_games_redone = 0;
+    int node_cap_auto = 0;           // 1: node_cap was derived from the free HBM (ao_config.node_cap == -1)
     // HIP-event timing of the per-simulation tree kernel (k_expand_select) on the launch stream
     bool timing = false;
     static constexpr int kRing = 256;
@@ -162,11 +168,15 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return e->fail("no HIP device available");
     if (c.device < 0 || c.device >= ndev) return e->fail("device ordinal out of range");
     AO_HIP(e, hipSetDevice(c.device));
-    if (c.node_cap <= 0) {
-        // Default arena: 4 x (sims + 1) expanded nodes per game is what a random-init network's searches need; a sharp
-        // (trained) policy keeps more of the tree from move to move, so the default grows into the HBM that is there --
-        // up to a quarter of the free memory, at most 16 x (sims + 1) -- before re-rooting has to forget subtrees
-        // (ao_trim_stats). 4096 games x 400 sims on a 288 GB part: ~3400 nodes per arena instead of 1604.
+    if (c.node_cap == 0) {
+        // Default arena: 4 x (sims + 1) expanded nodes per game -- what a random-init network's searches need, and a
+        // DETERMINISTIC number: whether re-rooting has to forget subtrees (ao_trim_stats) must not depend on what else
+        // happens to occupy the GPU when the engine is created.
+        c.node_cap = static_cast<int32_t>(std::min<long>(4L * (c.sims + 1), 15000));
+    } else if (c.node_cap < 0) {
+        // node_cap = -1, opt-in: grow into the HBM that is free right now -- up to a quarter of it, at most
+        // 16 x (sims + 1) -- for sharp (trained) policies that keep more of the tree from move to move. 4096 games x
+        // 400 sims on a 288 GB part: ~3400 nodes per arena instead of 1604. The chosen value is reported by ao_node_cap.
         const int Ap_ = (c.board * c.board + 15) / 16 * 16;
         const double node_bytes = Ap_ * 25.0 + 80.0;     // N, W, Q, CH 4 B + P 8 B + ACT 1 B per edge slot, + the position
         size_t free_b = 0, total_b = 0;
@@ -176,6 +186,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
             cap = std::max<long>(cap, std::min<long>(static_cast<long>(room), 16L * (c.sims + 1)));
         }
         c.node_cap = static_cast<int32_t>(std::min<long>(cap, 15000));
+        e->node_cap_auto = 1;
     }
     if (c.node_cap < c.sims + 2) return e->fail("node_cap must be at least sims + 2");
     if (c.node_cap > 15000) return e->fail("node_cap must be <= 15000");
@@ -219,6 +230,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         return 1;
     p.u8_row = A <= 128 ? 128 : 256;
     if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, G)) return 1;
+    if (dev_alloc(e, &e->d_mt_backup, static_cast<size_t>(G) * 624) || dev_alloc(e, &e->d_pos_backup, G)) return 1;
     p.row_of_game = nullptr;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
     p.batch_u8 = nullptr;
@@ -608,11 +620,19 @@ int ao_play(ao_engine* e, int32_t* action, int32_t* win) {
     return 0;
 }
 
-int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* tau, double* pi,
-              double* visit, double* policy) {
+static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* tau, double* pi,
+                       double* visit, double* policy, bool may_recover) {
     if (!net) return e->fail("ao_search: null network");
     std::string why;
     if (ao::net_check(net, e->cfg.board, e->cfg.inplanes, e->cfg.device, &why)) return e->fail("ao_search: " + why);
+    if (may_recover) {
+        // what the fp16-range recovery below needs to run this move again: the streams as they are NOW
+        AO_HIP(e, hipSetDevice(e->cfg.device));
+        AO_HIP(e, hipMemcpyAsync(e->d_mt_backup, e->tp.mt, sizeof(uint32_t) * 624 * e->G, hipMemcpyDeviceToDevice, e->stream));
+        AO_HIP(e, hipMemcpyAsync(e->d_pos_backup, e->tp.mtpos, sizeof(int32_t) * e->G, hipMemcpyDeviceToDevice, e->stream));
+        e->has_gauss_backup = e->has_gauss;
+        e->gauss_backup = e->gauss;
+    }
     // the network announces the interleaved input layout it wants for a batch of G boards
     if (ao_begin_move(e, active)) return 1;
     // The network runs on the ACTIVE games only: they are packed to the front of the evaluation batch (row_of_game), so
@@ -678,22 +698,69 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
         --e->sims_left;
     }
     if (rc) return rc;
-    // the split-fp16 trunk clamps activations beyond the fp16 range and reports it: such a move is not the
-    // fp32-equivalent evaluation the engine promises, so it fails loudly instead of returning numbers (checked before
-    // the per-game errors: clamped evaluations are what makes priors degenerate)
+    // The split-fp16 trunk clamps activations beyond the fp16 range and reports it: the evaluations of such a move are
+    // not the fp32-equivalent ones the engine promises (checked before the per-game errors: clamped evaluations are what
+    // makes priors degenerate). The move is then searched AGAIN, transparently, on the fp32-MFMA trunk: the games of this
+    // move get their pre-move MT19937 streams back and FRESH trees at their current positions (ao_set_roots semantics:
+    // what the search inherited from earlier moves is forgotten -- the one deviation from the reference, which would
+    // have searched on top of its inherited counts), the caller gets a result instead of an exception and the event is
+    // counted (ao_fp16_range_events; the Python layer turns it into a warning). The network returns to its previous
+    // mode afterwards; from the third event on it stays on the fp32-MFMA trunk (a checkpoint that keeps leaving the
+    // range would otherwise search every move twice).
     int32_t nflags = 0;
     if (ao_net_status(net, e->stream, &nflags, 1)) return e->fail(std::string("ao_net_status: ") + ao_net_last_error(net));
     if (nflags & AO_NET_FP16_RANGE) {
-        ao_net_set_mode(net, 2);
         (void)hipMemsetAsync(e->tp.err, 0, sizeof(int32_t) * e->G, e->stream);
         (void)hipStreamSynchronize(e->stream);
         e->in_move = false;
         e->ended = false;
-        return e->fail("ao_search: an activation left the fp16 range (|x| > 65504) in the split-fp16 trunk during this move, "
-                       "so its evaluations were clamped and are not fp32-equivalent; the network has been switched to the "
-                       "fp32-MFMA trunk (ao_net_set_mode 2) for all later calls -- reset the affected games and search again");
+        if (!may_recover)
+            return e->fail("ao_search: an activation left the fp16 range (|x| > 65504) in the split-fp16 trunk during the repeated move");
+        const int G = e->G;
+        std::vector<uint8_t> mask(G, 0);
+        std::vector<int32_t> games, ns;
+        std::vector<std::vector<int32_t>> saved;
+        for (int g = 0; g < G; ++g) {
+            if (!e->active[g]) continue;
+            mask[g] = 1;
+            games.push_back(g);
+            saved.push_back(e->moves[g]);
+            ns.push_back(static_cast<int32_t>(e->moves[g].size()));
+        }
+        std::vector<const int32_t*> ids;
+        for (auto& m : saved) ids.push_back(m.data());
+        AO_HIP(e, hipMemcpyAsync(e->tp.mt, e->d_mt_backup, sizeof(uint32_t) * 624 * G, hipMemcpyDeviceToDevice, e->stream));
+        AO_HIP(e, hipMemcpyAsync(e->tp.mtpos, e->d_pos_backup, sizeof(int32_t) * G, hipMemcpyDeviceToDevice, e->stream));
+        e->has_gauss = e->has_gauss_backup;
+        e->gauss = e->gauss_backup;
+        if (ao_reset(e, mask.data())) return 1;
+        if (set_roots_impl(e, static_cast<int>(games.size()), games.data(), ids.data(), ns.data(), nullptr)) return 1;
+        const int prev_mode = ao_net_get_mode(net);
+        ao_net_set_mode(net, 2);
+        ++e->fp16_events;
+        e->fp16_games_redone += static_cast<int64_t>(games.size());
+        const int rc2 = search_impl(e, net, active, tau, pi, visit, policy, false);
+        if (e->fp16_events < 3) ao_net_set_mode(net, prev_mode);
+        return rc2;
     }
     return ao_end_move(e, tau, pi, visit, policy);
+}
+
+int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* tau, double* pi,
+              double* visit, double* policy) {
+    return search_impl(e, net, active, tau, pi, visit, policy, true);
+}
+
+int ao_fp16_range_events(ao_engine* e, int64_t* moves_repeated, int64_t* games_redone) {
+    if (moves_repeated) *moves_repeated = e->fp16_events;
+    if (games_redone) *games_redone = e->fp16_games_redone;
+    return 0;
+}
+
+int ao_node_cap(ao_engine* e, int32_t* node_cap, int32_t* from_free_memory) {
+    if (node_cap) *node_cap = e->cfg.node_cap;
+    if (from_free_memory) *from_free_memory = e->node_cap_auto;
+    return 0;
 }
 
 // ---- introspection ---------------------------------------------------------------------------

@@ -70,6 +70,7 @@ struct ao_net {
     double ms_total = 0.0;
     int64_t launches = 0;
     int last_in_kind = 1;                          // input of the most recent forward: 1 fp32 plane batch, 2 the engine's bit planes
+    int trunk_fmt = -1;                            // activation format inside the resident split-fp16 trunk (kPairBytes): -1 = by depth (3 bytes up to 6 ResBlocks, else 4), 0 / 1 forced (AO_TRUNK_FMT)
 
     int fail(const std::string& m) { err = m; return 1; }
 };
@@ -454,14 +455,23 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         constexpr size_t rows_ = static_cast<size_t>(2) * W * 4 * 2 * 1024 + 64;   /* two row buffers + the split-barrier counter */ \
         constexpr size_t lds_ = (rows_ > heads_) ? rows_ : heads_;                                            \
         if (!n->attr_done[W]) {                                                                                 \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4>),              \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4, 0>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16hb<W, 4>),              \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16hb<W, 4, 0>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16h<W, 4, 1>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trunk16hb<W, 4, 1>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_))); \
             n->attr_done[W] = true;                                                                           \
         }                                                                                                    \
-        if (in_kind == 2) hipLaunchKernelGGL((k_trunk16hb<W, 4>), dim3(groups), dim3(512), lds_, s, a);    \
-        else hipLaunchKernelGGL((k_trunk16h<W, 4>), dim3(groups), dim3(512), lds_, s, a);                 \
+        if (n->trunk_fmt == 1) {                                                                             \
+            if (in_kind == 2) hipLaunchKernelGGL((k_trunk16hb<W, 4, 1>), dim3(groups), dim3(512), lds_, s, a);    \
+            else hipLaunchKernelGGL((k_trunk16h<W, 4, 1>), dim3(groups), dim3(512), lds_, s, a);                 \
+        } else {                                                                                             \
+            if (in_kind == 2) hipLaunchKernelGGL((k_trunk16hb<W, 4, 0>), dim3(groups), dim3(512), lds_, s, a);    \
+            else hipLaunchKernelGGL((k_trunk16h<W, 4, 0>), dim3(groups), dim3(512), lds_, s, a);                 \
+        }                                                                                                    \
     } break;
             AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
 #undef AO_BW_CASE
@@ -593,6 +603,10 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             n->num_cu = prop.multiProcessorCount;
     }
+    if (const char* v = getenv("AO_TRUNK_FMT")) n->trunk_fmt = atoi(v) == 1 ? 1 : 0;
+    // 19-bit activations cost ~8 x the rounding error of the two-half format (profiles/r3a_*): measured against fp64 on the
+    // golden-vector networks 1.8e-5 at 4 blocks, 3.5e-5 at 10 -- the deeper networks keep the 4-byte format
+    if (n->trunk_fmt < 0) n->trunk_fmt = n_block <= 6 ? 1 : 0;
     if (const char* v = getenv("AO_XT")) n->force_xt = atoi(v) == 4 ? 4 : (atoi(v) == 5 ? 5 : 0);
     if (const char* v = getenv("AO_NCH")) n->force_nch = atoi(v) > 0 && atoi(v) <= board ? atoi(v) : 0;
     *out = n;
@@ -618,6 +632,8 @@ int ao_net_set_mode(ao_net* n, int mode) {
     n->mode = mode;
     return 0;
 }
+
+int ao_net_get_mode(const ao_net* n) { return n->mode; }
 
 int ao_net_set_param(ao_net* n, const char* name, const float* data, int64_t numel) {
     if (!name || (!data && numel > 0) || numel < 0) return n->fail("bad argument");
@@ -881,8 +897,9 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
              "16-board groups x row chunks x column tiles)";
         f = conv;
     } else if (group == 16 && mode == 5) {
-        nm = std::string(in_kind == 2 ? "k_trunk16hb<" : "k_trunk16h<") + bw + ", 4> (conv1 + " + std::to_string(2 * n->nb) +
-             " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate) + heads, one resident launch)";
+        nm = std::string(in_kind == 2 ? "k_trunk16hb<" : "k_trunk16h<") + bw + ", 4, " + std::to_string(n->trunk_fmt) + "> (conv1 + " +
+             std::to_string(2 * n->nb) + " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate) + heads, one resident "
+             "launch; activations between layers as " + (n->trunk_fmt == 1 ? "fp16 high half + one low byte" : "two fp16 halves") + ")";
         f = conv1 + 2.0 * n->nb * conv;
     } else if (group == 16) {
         nm = "k_trunk16<" + bw + "> (conv1 + " + std::to_string(2 * n->nb) + " 3x3 convs, one launch, fp32 MFMA 16x16x4)";
@@ -924,6 +941,8 @@ int ao_net_plan_kernel(int n_block, int inplanes, int planes, int board, int tru
     n.nchq1 = (((inplanes + 3) / 4) + 3) & ~3;
     n.CQ = planes / 4;
     n.mode = trunk_mode;
+    if (const char* v = getenv("AO_TRUNK_FMT")) n.trunk_fmt = atoi(v) == 1 ? 1 : 0;
+    if (n.trunk_fmt < 0) n.trunk_fmt = n_block <= 6 ? 1 : 0;   // as ao_net_create
     std::string nm;
     double f = 0.0;
     dominant_name(&n, boards, in_kind, &nm, &f);

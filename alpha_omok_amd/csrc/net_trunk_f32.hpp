@@ -342,8 +342,9 @@ __device__ __forceinline__ void trunk_layer(const float4* __restrict__ src, floa
 // Policy and value heads of one 16-board group inside the resident kernel (model.py:34-73):
 // 1x1 convs + BN + ReLU into LDS (flatten order c*A + cell, as the reference's .view), then one
 // wave per board: policy_fc + softmax, value_fc1 + ReLU + value_fc2 + tanh.
-// H16: the activations are in the split-fp16 layout of k_trunk16h (x = high half + low half)
-template <int BW, bool H16 = false, typename Args = TrunkArgs>
+// H16: 1 = the activations are in the split-fp16 layout of k_trunk16h (x = high half + low half), 2 = its 3-byte form
+// (fp16 high half + one low byte, kPairBytes(1) in net_trunk_h16.hpp), 0 = fp32
+template <int BW, int H16 = 0, typename Args = TrunkArgs>
 __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, size_t gbase, int grp) {
     constexpr int A = BW * BW;
     constexpr int GB = 16;
@@ -362,7 +363,19 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int cq = 0; cq < CQ; ++cq) {
                 float4 x;
-                if (H16) {
+                if (H16 == 2) {
+                    // [cell][c32]{[oct 4][board 16][8 halfs] | [oct 4][board 16][8 bytes]}: 1536 B per (cell, block)
+                    const char* base = reinterpret_cast<const char*>(act) + ((gbase + cell) * (CQ >> 3) + (cq >> 3)) * 1536;
+                    const int slot = ((cq & 7) >> 1) * 16 + b;
+                    const uint2 hw = *reinterpret_cast<const uint2*>(base + slot * 16 + (cq & 1) * 8);
+                    const unsigned lw = *reinterpret_cast<const unsigned*>(base + 1024 + slot * 8 + (cq & 1) * 4);
+                    auto val = [](unsigned h, unsigned l) {
+                        const unsigned t = (h << 8) | l;
+                        return __uint_as_float(t ? (t << 5) + 0x38000000u : 0u);
+                    };
+                    x = make_float4(val(hw.x & 0xffffu, lw & 0xffu), val(hw.x >> 16, (lw >> 8) & 0xffu),
+                                    val(hw.y & 0xffffu, (lw >> 16) & 0xffu), val(hw.y >> 16, lw >> 24));
+                } else if (H16) {
                     // [cell][c32][split][kq 4][board 16][8 halfs]: quad cq = halfs (cq&1)*4.. of oct (cq&7)>>1 of block cq>>3
                     const char* base = reinterpret_cast<const char*>(act) +
                                        ((((gbase + cell) * (CQ >> 3) + (cq >> 3)) * 2) * 64 + ((cq & 7) >> 1) * 16 + b) * 16 +

@@ -73,7 +73,9 @@ __device__ unsigned long long ao_prof[8 * 12];
 // 2 LDS operand fragments read once per slab, 3 no staging of input rows, 4 no row epilogues (residual loads +
 // stores), 5 / 6 activations of all groups aliased to an 85 / 170 MB footprint, 8 no heads, 10 the low halves move half
 // their bytes (staged by lanes 0-31 only, stored / re-read as 4 bytes per lane: the traffic of a 3-byte activation format
-// without its conversion work). Measured: profiles/r1j_trunk16h_phase_timing.txt, r3a_trunk16h_bytes_ko.txt
+// without its conversion work; BUT the unstaged half of every low fragment then keeps conv1's zeros in LDS, and an MFMA
+// on zeros draws less power), 12 the same traffic with the staged 512 bytes loaded twice so that every operand stays
+// data-like. Measured: profiles/r1j_trunk16h_phase_timing.txt, r3a_trunk16h_bytes_ko.txt
 #ifndef AO_KO
 #define AO_KO 0
 #endif
@@ -110,7 +112,30 @@ __device__ __forceinline__ void row_wait(unsigned* cnt, unsigned target) {
 // BIT planes: one byte per (board, cell), bit q = plane q ([board 16][kPlaneRow(BW)] bytes per group) -- the planes are
 // 0/1, so 81 bytes per leaf carry what the fp32 batch spends 2.6 KB on (tree_device.hpp encode_planes).
 __host__ __device__ constexpr int kPlaneRow(int bw) { return bw * bw <= 128 ? 128 : 256; }
-template <int BW, int NC32, int NCI, int KIND>
+// FMT: how the trunk activations of the RESIDENT kernel live in HBM between its layers (private to one launch):
+//   0  two fp16 halves, x = xh + xl: 2 KB per (cell, 32-channel block) of a 16-board group, ~22 significand bits
+//   1  fp16 high half + ONE low byte: 1.5 KB per (cell, block), 19 significand bits. Activations are post-ReLU (x >= 0):
+//      with t = RNE_19bit(x) as the 24-bit word [E5 | M18] (fp32 bits re-biased to fp16's exponent), the high half is
+//      t >> 8 -- a valid fp16, the TRUNCATION of the rounded value -- and the low byte is t & 255, the next 8 mantissa
+//      bits, i.e. xl = byte * 2^(E5 - 33) >= 0. The high halves are still staged by LDS-direct loads; the low bytes are
+//      staged into the first half of their LDS slot and expanded in place to the fp16 fragment the MFMAs read (one
+//      conversion per element and layer, by the wave that staged it). 25 % fewer activation bytes per pass:
+//      profiles/r3a_trunk16h_bytes_ko.txt (-15 % launch time as a traffic knock-out), numerics gate
+//      profiles/r3a_lo8_numerics_emulation.txt (tools/emulate_lo8_storage.py).
+__host__ __device__ constexpr unsigned kPairBytes(int fmt) { return fmt == 1 ? 1536u : 2048u; }
+
+// The epilogue of format 1 works on activations SCALED BY 2^-112 (folded into the BatchNorm scale / shift): an fp32 number
+// v' = x * 2^-112 carries fp16's exponent field directly (E8 = E5 for 2^-14 <= x < 65536), so the 24-bit word is its bits
+// >> 5 after rounding to nearest even at bit 5, no re-biasing; x < 2^-14 (v' below the smallest normal fp32) is flushed to
+// zero. Decoding is the reverse: as_float(word << 5) IS x * 2^-112, ready to be added to the scaled BatchNorm output.
+constexpr float kLo8Scale = 0x1p-112f;
+__device__ __forceinline__ float lo8_scaled(unsigned h, unsigned l) { return __uint_as_float(((h << 8) | l) << 5); }
+__device__ __forceinline__ unsigned lo8_word(float vs) {   // vs: scaled, clamped to [0, 65504 * 2^-112], 0 below 2^-126
+    const unsigned u = __float_as_uint(vs);
+    return (u + 15u + ((u >> 5) & 1u)) >> 5;
+}
+
+template <int BW, int NC32, int NCI, int KIND, int FMT = 0>
 struct TrunkHLayerFn {
 static __device__ __forceinline__ void run(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
                                            int tile, int lane, unsigned long long* prof, const bool flip,
@@ -127,16 +152,22 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
     constexpr int NFR = BW * NCI * NSP;      // input fragments per board row
     constexpr int NB = NCI * 3;              // (32-channel block, tap row) slabs per input row
     constexpr int NPR = 3;                   // MFMA products per multiply-add
+    constexpr int PAIR = static_cast<int>(kPairBytes(FMT));   // bytes of a (cell, block) fragment pair in HBM
+    constexpr int NPAIR = BW * NCI;          // fragment pairs per board row
     const int kq = lane >> 4, b = lane & 15;
     const int lane16 = lane * 16;
     // per-lane byte offset of this lane's 4 output channels inside a (cell, 32-channel block) fragment pair
     const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
-    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    if (FMT == 1) {   // the epilogue runs on x * 2^-112 (see lo8_word)
+        sc.x *= kLo8Scale; sc.y *= kLo8Scale; sc.z *= kLo8Scale; sc.w *= kLo8Scale;
+        sh.x *= kLo8Scale; sh.y *= kLo8Scale; sh.z *= kLo8Scale; sh.w *= kLo8Scale;
+    }
     const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
     const __amdgpu_buffer_rsrc_t rs_src =
-        make_rsrc(src, BITS ? 16u * kPlaneRow(BW) : FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * 2u * 1024u);
-    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+        make_rsrc(src, BITS ? 16u * kPlaneRow(BW) : FIRST ? static_cast<unsigned>(A) * 8u * 16u * 16u : static_cast<unsigned>(A) * NCI * kPairBytes(FMT));
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * kPairBytes(FMT));
     // weights of slab (c, dy): 3 taps x {high, low}, streamed from L2 one slab ahead (the other wave of the
     // SIMD computes meanwhile)
     // (conv1 has a single 32-channel block: its 9 x 2 fragments are simply loaded once)
@@ -197,17 +228,21 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
 #pragma unroll
         for (int i0 = 0; i0 < BW; i0 += HB) {
             half4 rh[HB], rl[HB];
+            unsigned rb[HB];   // FMT 1: the four low bytes of the residual
             if (RES) {
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     const int i = i0 + k < BW ? i0 + k : BW - 1;
-                    const int ob = (((py(yo) * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                    const int ob = ((py(yo) * BW + i) * NC32 + (tile >> 1)) * PAIR;
                     rh[k] = buf_ld_h4(rs_dst, out_voff, ob);
-                    if (AO_KO == 10) {
+                    if (FMT == 1) {
+                        rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_dst, out_voff >> 1, ob + 1024, AO_AUX_RES);
+                    } else if (AO_KO == 10 || AO_KO == 12) {
                         const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rs_dst, out_voff >> 1, ob + 1024, AO_AUX_RES);
                         rl[k] = __builtin_bit_cast(half4, u32x2{u, u});
-                    } else
-                    rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+                    } else {
+                        rl[k] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+                    }
                 }
             }
 #pragma unroll
@@ -216,13 +251,31 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                 if (i >= BW) continue;
                 const f32x4 c = acc[0][i];
                 float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
-                const int ob = (((py(yo) * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+                const int ob = ((py(yo) * BW + i) * NC32 + (tile >> 1)) * PAIR;
                 if (RES) {
+                    if (FMT == 1) {
+                        const u32x2 hb = __builtin_bit_cast(u32x2, rh[k]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
+                        for (int r = 0; r < 4; ++r)
+                            f[r] += lo8_scaled((hb[r >> 1] >> (16 * (r & 1))) & 0xffffu, (rb[k] >> (8 * r)) & 0xffu);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[k][r]) + static_cast<float>(rl[k][r]);
+                    }
+                }
+                peak = fmaxf(fmaxf(peak, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
+                if (FMT == 1) {
+                    unsigned t[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)   // ReLU + flush below 2^-14 (the smallest normal fp32 in the scaled domain), upper clamp
+                        t[r] = lo8_word(f[r] >= 0x1p-126f ? fminf(f[r], 65504.f * kLo8Scale) : 0.f);
+                    const u32x2 hw = {(t[0] >> 8) | ((t[1] >> 8) << 16), (t[2] >> 8) | ((t[3] >> 8) << 16)};
+                    const unsigned lw = (t[0] & 0xffu) | ((t[1] & 0xffu) << 8) | ((t[2] & 0xffu) << 16) | (t[3] << 24);
+                    __builtin_amdgcn_raw_buffer_store_b64(hw, rs_dst, out_voff, ob, AO_AUX_ST);
+                    __builtin_amdgcn_raw_buffer_store_b32(lw, rs_dst, out_voff >> 1, ob + 1024, AO_AUX_ST);
+                    continue;
                 }
                 half4 hh, hl;
-                peak = fmaxf(fmaxf(peak, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // ReLU; the upper clamp keeps an activation beyond the fp16 range (65504 -- far outside what a
@@ -233,9 +286,55 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                     hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
                 }
                 buf_st_h4(hh, rs_dst, out_voff, ob);
-                if (AO_KO == 10) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32x2, hl)[0], rs_dst, out_voff >> 1, ob + 1024, AO_AUX_ST);
+                if (AO_KO == 10 || AO_KO == 12) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(u32x2, hl)[0], rs_dst, out_voff >> 1, ob + 1024, AO_AUX_ST);
                 else
                 buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+            }
+        }
+    };
+    // FMT 1 staging of input row y into row buffer xb: wave w owns fragment PAIRS w, w + NT, ... -- the high half by an
+    // LDS-direct load of all 64 lanes, the 512 low bytes by lanes 0-31 into the first half of the pair's low slot
+    auto stage_pairs = [&](int y, uint4* xb, int k0, int k1) {
+#pragma unroll
+        for (int k = k0; k < k1; ++k) {
+            const int p = tile + NT * k;
+            if (p < NPAIR) {
+                const int so = (py(y) * NPAIR + p) * PAIR;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + (2 * p) * 64), 16, lane16,
+                                                         so, 0, AO_AUX_STAGE);
+                if (lane < 32)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + (2 * p + 1) * 64), 16,
+                                                             lane16, so + 1024, 0, AO_AUX_STAGE);
+            }
+        }
+    };
+    // ... and, once those loads have landed (s_waitcnt vmcnt(0) of THIS wave: it staged both halves of its pairs), the
+    // expansion of the low bytes to the fp16 low-half fragment, in place: xl = byte * 2^(E5 - 33), exact in fp16 (down to
+    // its subnormal quantum, which the MFMA honours: tools/mfma_denorm.hip). DS operations of a wave execute in order, so
+    // every lane's 8-byte read of the slot precedes the 16-byte writes.
+    auto expand_pairs = [&](uint4* xb, int k0, int k1) {
+        // per dword (two channels): y = 1024 + byte as fp16 (0x6400 | byte), c = y * 2^-18 - 2^-8 = byte * 2^-18 (exact, one
+        // rounding), xl = c * 2^(E5-15), the second factor being the high half with its mantissa cleared
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        const half2v k18 = {static_cast<_Float16>(0x1p-18f), static_cast<_Float16>(0x1p-18f)};
+        const half2v m8 = {static_cast<_Float16>(-0x1p-8f), static_cast<_Float16>(-0x1p-8f)};
+#pragma unroll
+        for (int k = k0; k < k1; ++k) {
+            const int p = tile + NT * k;
+            if (p < NPAIR) {
+                const uint4 hv = xb[(2 * p) * 64 + lane];
+                const u32x2 lv = reinterpret_cast<const u32x2*>(xb + (2 * p + 1) * 64)[lane];
+                const unsigned hw[4] = {hv.x, hv.y, hv.z, hv.w};
+                unsigned ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // bytes (2j, 2j+1) of the 8 low bytes -> 0x64 b1 0x64 b0
+                    const unsigned y = __builtin_amdgcn_perm(0x64646464u, lv[j >> 1], (j & 1) ? 0x04030402u : 0x04010400u);
+                    const half2v c = __builtin_elementwise_fma(__builtin_bit_cast(half2v, y), k18, m8);
+                    const half2v sc2 = __builtin_bit_cast(half2v, hw[j] & 0x7c007c00u);
+                    ow[j] = __builtin_bit_cast(unsigned, c * sc2);
+                }
+                xb[(2 * p + 1) * 64 + lane] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
         }
     };
@@ -252,18 +351,25 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
             const int f = tile + NT * k;
             if (f < NFR) s_x[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(f >> 1, f & 1));
         }
+    } else if (FMT == 1) {
+        stage_pairs(0, s_x, 0, (NPAIR + NT - 1) / NT);
     } else {
 #pragma unroll
         for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
             const int f = tile + NT * k;
             if (f < NFR && !(AO_KO == 10 && (f & 1) && lane >= 32))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16,
+                                                         (AO_KO == 12 && (f & 1) && lane >= 32) ? lane16 - 512 : lane16,
                                                          (py(0) * NFR + f) * 1024, 0, AO_AUX_STAGE);
         }
     }
     AO_T(t_a2);
     load_w(0, wA);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (FMT == 1 && !FIRST) {
+        expand_pairs(s_x, 0, (NPAIR + NT - 1) / NT);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     AO_T(t_a3);
     __syncthreads();
     AO_T(t_b);
@@ -285,7 +391,14 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
             half8 (&w)[2][3] = (slab & 1) ? wB : wA;
             half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
             load_w(slab + 1, wn);
-            if (dy == 1 && AO_KO != 3) {
+            if (dy == 1 && AO_KO != 3 && FMT == 1 && !FIRST) {
+                // next input row into LDS, a share of this wave's fragment pairs per block
+                // (the share staged one block earlier has landed long ago: it is expanded first, so that the wait the
+                // compiler puts in front of its LDS reads does not cover the loads issued below)
+                constexpr int K2 = (NPAIR / NT + NCI - 1) / (NCI > 1 ? NCI - 1 : 1);   // shares in blocks 0 .. NCI-2, the last block only expands
+                if (c > 0 && AO_KO != 11) expand_pairs(xn, (c - 1) * K2, c * K2);   // (AO_KO 11: no expansion, timing only)
+                if (c + 1 < NCI) stage_pairs(yn, xn, c * K2, (c + 1) * K2);
+            } else if (dy == 1 && AO_KO != 3) {
                 // next input row into LDS, a share per block (always-executed slab)
 #pragma unroll
                 for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
@@ -294,7 +407,8 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                         if (FIRST) xn[f * 64 + lane] = __builtin_bit_cast(uint4, load_planes(yn * BW + (f >> 1), f & 1));
                         else if (!(AO_KO == 10 && (f & 1) && lane >= 32))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xn + f * 64),
-                                                                     16, lane16, (py(yn) * NFR + f) * 1024, 0, AO_AUX_STAGE);
+                                                                     16, (AO_KO == 12 && (f & 1) && lane >= 32) ? lane16 - 512 : lane16,
+                                                                     (py(yn) * NFR + f) * 1024, 0, AO_AUX_STAGE);
                     }
                 }
             }
@@ -359,7 +473,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
     }
     AO_T(t_c);
     epilogue(BW - 1);
-    if (peak > 65504.f) atomicOr(L.ovf, 1);
+    if (peak > (FMT == 1 ? 65504.f * kLo8Scale : 65504.f)) atomicOr(L.ovf, 1);
     // layer boundary inside the workgroup (see k_trunk16)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -589,17 +703,18 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
     }
 }
 
-template <int BW, int NC32, int INK>   // INK: 1 fp32 plane batch, 2 bit planes (see trunk_h_layer)
+template <int BW, int NC32, int INK, int FMT>   // INK: 1 fp32 plane batch, 2 bit planes (see trunk_h_layer); FMT: see kPairBytes
 __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
+    static_assert(FMT == 0 || AO_SPLIT_BARRIER == 0, "the split row barrier is implemented for the 4-byte format only");
     constexpr int A = BW * BW;
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][row fragments][64] uint4
     const int grp = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
-    // first activation fragment of this group (AO_KO 5 / 6: groups share buffers, timing experiment only)
-    const size_t gfrag = static_cast<size_t>(AO_KO == 5 ? grp % 64 : AO_KO == 6 ? grp % 128 : grp) * A * NC32 * 2;
-    uint4* bufA = a.bufA + gfrag * 64;
-    uint4* bufB = a.bufB + gfrag * 64;
+    // first activation byte of this group, in uint4 units (AO_KO 5 / 6: groups share buffers, timing experiment only)
+    const size_t gq = static_cast<size_t>(AO_KO == 5 ? grp % 64 : AO_KO == 6 ? grp % 128 : grp) * A * NC32 * (kPairBytes(FMT) / 16);
+    uint4* bufA = a.bufA + gq;
+    uint4* bufB = a.bufB + gq;
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long* pp = prof;
     // arrival counter of the split row barrier: behind the two row buffers (kTrunkHCntOffset), monotonic over the launch
@@ -608,10 +723,10 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     // conv1: fp32 planes -> x
     AO_T(t0);
     if (INK == 2)
-        TrunkHLayerFn<BW, NC32, 1, 2>::run(reinterpret_cast<const uint8_t*>(a.in0) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), bufA,
+        TrunkHLayerFn<BW, NC32, 1, 2, FMT>::run(reinterpret_cast<const uint8_t*>(a.in0) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), bufA,
                                       a.layers[0], false, s_x, tile, lane, pp, false, s_cnt, 0u);
     else
-        TrunkHLayerFn<BW, NC32, 1, 1>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
+        TrunkHLayerFn<BW, NC32, 1, 1, FMT>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
                                       s_cnt, 0u);
     AO_T(t1);
 #ifdef AO_PROF
@@ -620,11 +735,11 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     for (int l = 1; l < a.nlayers; ++l) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
-        TrunkHLayerFn<BW, NC32, NC32, 0>::run(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
+        TrunkHLayerFn<BW, NC32, NC32, 0, FMT>::run(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
                                              (l & 1) != 0, s_cnt, static_cast<unsigned>(l) * BW);
     }
     AO_T(t2);
-    if (AO_KO != 8) trunk_heads<BW, true>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
+    if (AO_KO != 8) trunk_heads<BW, FMT == 1 ? 2 : 1>(a, reinterpret_cast<const float4*>(a.bufA), static_cast<size_t>(grp) * A, grp);
 #ifdef AO_PROF
     AO_T(t3);
     prof[5] = t3 - t2;
@@ -636,13 +751,13 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
 }
 
 // conv1 on the fp32 plane batch (ao_net_forward: any float planes) / on the engine's bit planes (ao_search)
-template <int BW, int NC32>
+template <int BW, int NC32, int FMT>
 __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
-    trunk16h_body<BW, NC32, 1>(a);
+    trunk16h_body<BW, NC32, 1, FMT>(a);
 }
-template <int BW, int NC32>
+template <int BW, int NC32, int FMT>
 __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16hb(TrunkHArgs a) {
-    trunk16h_body<BW, NC32, 2>(a);
+    trunk16h_body<BW, NC32, 2, FMT>(a);
 }
 
 }  // namespace ao

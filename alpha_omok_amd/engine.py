@@ -146,6 +146,7 @@ class Engine:
         self.board_size, self.num_mcts, self.inplanes, self.G = board_size, num_mcts, inplanes, games
         self.A = board_size * board_size
         self.device = device
+        self._fp16_seen = self._fp16_games_seen = 0
 
     def _check(self, rc, what):
         if rc:
@@ -252,7 +253,27 @@ class Engine:
         self._check(self._L.ao_search(self._h, net._h, _ptr(a, C.c_uint8), _ptr(t, C.c_int8),
                                       _ptr(pi, C.c_double), _ptr(vis, C.c_double), _ptr(pol, C.c_double)),
                     "ao_search")
+        ev, games = self.fp16_range_events()
+        if ev != self._fp16_seen:
+            import warnings
+            warnings.warn("the split-fp16 trunk met an activation beyond the fp16 range (|x| > 65504): this move was searched "
+                          "again on the fp32-MFMA trunk with fresh trees for its %d games (%d such move(s) so far; from the "
+                          "third on the network stays on the fp32-MFMA trunk)" % (games - self._fp16_games_seen, ev),
+                          RuntimeWarning, stacklevel=2)
+            self._fp16_seen, self._fp16_games_seen = ev, games
         return pi, vis, pol
+
+    def fp16_range_events(self):
+        """(moves ao_search repeated on the fp32-MFMA trunk, games searched again) since the engine was created."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._L.ao_fp16_range_events(self._h, C.byref(a), C.byref(b)), "ao_fp16_range_events")
+        return a.value, b.value
+
+    def node_cap(self):
+        """(expanded-node capacity of one game's arena, True if it was derived from the free HBM: node_cap=-1)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self._L.ao_node_cap(self._h, C.byref(a), C.byref(b)), "ao_node_cap")
+        return a.value, bool(b.value)
 
     # -- introspection
     def root_children(self, game):

@@ -35,8 +35,9 @@ typedef struct ao_config {
     int32_t inplanes;   /* IN_PLANES = 2*history+1 (main.py:34); 3, 5, 7 or 9                  */
     int32_t games;      /* G concurrent games (1 for a drop-in ZeroAgent)                      */
     int32_t noise;      /* Dirichlet root noise on/off (agents.py:40,49)                       */
-    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = 4*(sims+1) .. 16*(sims+1), as a quarter of
-                           the free HBM allows; see ao_trim_stats                                              */
+    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = 4*(sims+1) (deterministic default),
+                           -1 = grow into the free HBM (a quarter of it, at most 16*(sims+1)); see ao_trim_stats,
+                           ao_node_cap                                                                        */
     int32_t device;     /* HIP device ordinal                                                  */
     double  c_puct;     /* 0 = 5 (agents.py:48)                                                */
     double  alpha;      /* 0 = 10/board^2 (agents.py:47)                                       */
@@ -136,6 +137,13 @@ int ao_tree_timing(ao_engine *e, int enable, double *ms_total, int64_t *launches
  * reference's never-pruned dict, and only in games that hit the limit). subtrees_dropped / reroots_trimmed count the
  * events; both stay 0 while node_cap is large enough (raise ao_config.node_cap otherwise). */
 int ao_trim_stats(ao_engine *e, int64_t *subtrees_dropped, int64_t *reroots_trimmed);
+/* the arena capacity this engine runs with (ao_config.node_cap after defaults) and whether it was derived from the free
+ * HBM at creation (node_cap = -1): what decides if agents.py's never-pruned dict (agents.py:52) is reproduced in full. */
+int ao_node_cap(ao_engine *e, int32_t *node_cap, int32_t *from_free_memory);
+/* ao_search repeats a move on the fp32-MFMA trunk when the split-fp16 trunk met an activation beyond the fp16 range
+ * (ao_net_status): the games of that move get their pre-move streams back and fresh trees at their positions, the
+ * caller gets the repeated move's result. Counted here since ao_create: moves repeated, games searched again. */
+int ao_fp16_range_events(ao_engine *e, int64_t *moves_repeated, int64_t *games_redone);
 /* search-shape counters since the last ao_begin_move, summed over games: PUCT levels traversed,
  * k>1 random tie-breaks, terminal leaves, evaluated leaves */
 int ao_search_stats(ao_engine *e, int64_t *levels, int64_t *ties, int64_t *terminal,
@@ -167,11 +175,12 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
  * over (16-board group x row chunk x column tile) (any board up to 15x15, smaller batches), and is
  * what mode 0 picks on such a net for batches of more than ~3800 cells (47 9x9 boards). */
 int  ao_net_set_mode(ao_net *n, int mode);
+int  ao_net_get_mode(const ao_net *n);
 /* Status word of the network, read on `stream` (which is synchronised): AO_NET_FP16_RANGE is set when the
  * split-fp16 trunk (modes 0 / 5 at 128 planes) met an activation beyond the fp16 range and clamped it to 65504 --
  * the outputs of such a forward are finite but not the fp32-equivalent evaluation of model.py:76-104. clear != 0
- * resets the word. ao_search checks it after every move, fails that move and switches the network to the
- * fp32-MFMA trunk (mode 2). */
+ * resets the word. ao_search checks it after every move and repeats such a move on the fp32-MFMA trunk (mode 2),
+ * see ao_fp16_range_events. */
 enum { AO_NET_FP16_RANGE = 1 };
 int  ao_net_status(ao_net *n, void *stream, int32_t *flags, int clear);
 /* total device time (ms) and launch count of the dominant trunk kernel since the last call
