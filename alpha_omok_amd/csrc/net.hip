@@ -681,6 +681,7 @@ static std::vector<float> pack_conv(const std::vector<float>& w, int cout, int c
 // OIHW fp32 -> two fp16 planes [tap][c32][tile][oct 4][cout 16][8]: w * 2^s = high + low
 static void pack_conv_h(const std::vector<float>& w, int cout, int cin, int s, std::vector<uint16_t>* hi,
                         std::vector<uint16_t>* lo) {
+    static const int wl_drop_bits = [] { const char* v = getenv("AO_WL_BITS"); const int b = v ? atoi(v) : 11; return b >= 1 && b < 11 ? 11 - b : 0; }();
     const int nc32 = cin / 32, nt = cout / 16;
     hi->assign(static_cast<size_t>(9) * nc32 * nt * 64 * 8, 0);
     lo->assign(hi->size(), 0);
@@ -690,7 +691,14 @@ static void pack_conv_h(const std::vector<float>& w, int cout, int cin, int s, s
             for (int t = 0; t < 9; ++t) {
                 const float v = w[(static_cast<size_t>(co) * cin + ci) * 9 + t] * scale;
                 const _Float16 h = static_cast<_Float16>(v);
-                const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+                _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+                if (wl_drop_bits > 0) {   // experiment (AO_WL_BITS): round the low half to fewer significant bits (less MFMA operand activity)
+                    uint16_t b;
+                    std::memcpy(&b, &l, 2);
+                    const uint16_t half = static_cast<uint16_t>(1u << (wl_drop_bits - 1));
+                    b = static_cast<uint16_t>((b + (half - 1) + ((b >> wl_drop_bits) & 1u)) & ~((1u << wl_drop_bits) - 1u));
+                    std::memcpy(&l, &b, 2);
+                }
                 const size_t idx = ((((static_cast<size_t>(t) * nc32 + ci / 32) * nt + co / 16) * 4 + (ci % 32) / 8) * 16 +
                                     co % 16) * 8 + ci % 8;
                 std::memcpy(&(*hi)[idx], &h, 2);

@@ -159,63 +159,78 @@ int ao_replay_clear(ao_replay* r) {
     return 0;
 }
 
-int ao_replay_extend(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
-                     void* stream) {
-    if (n < 0) return r->fail("ao_replay_extend: negative sample count");
-    if (n == 0) return 0;
+// `skipped` samples logically precede the n given ones in this call but are not supplied: the caller knows that every
+// entry of theirs would be overwritten by the given ones (n * nsym >= capacity), so only ring positions move for them.
+static int extend_impl(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
+                       int64_t skipped, void* stream) {
+    if (n < 0 || skipped < 0) return r->fail("ao_replay_extend: negative sample count");
+    if (n == 0 && skipped == 0) return 0;
     const int nsym = augment ? 8 : 1;
     if (r->cap < nsym) return r->fail("ao_replay_extend: capacity below one augmented sample (8 entries)");
+    if (skipped > 0 && n * nsym < r->cap)
+        return r->fail("ao_replay_extend_skip: the given samples do not fill the memory, so skipped ones would survive");
     RP_HIP(r, hipSetDevice(r->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t CA = static_cast<int64_t>(r->C) * r->A;
     // Only the newest `cap` entries of this call can survive (deque(maxlen) semantics); the slots
     // are written as if every entry had been appended in turn.
-    if (n > r->st_n) {
+    const int64_t total = n * nsym;
+    // entries of this call that are already overwritten by later entries of the same call are skipped:
+    // whole samples from the first one that survives at least partially are staged and written
+    const int64_t skip = std::max<int64_t>(0, total - r->cap);
+    const int64_t first_smp = skip / nsym;
+    const int64_t n_st = n - first_smp;
+    if (n_st > r->st_n) {
         for (void* p : {static_cast<void*>(r->st_s), static_cast<void*>(r->st_pi), static_cast<void*>(r->st_z)})
             if (p) hipFree(p);
         r->st_s = nullptr; r->st_pi = nullptr; r->st_z = nullptr; r->st_n = 0;
-        RP_HIP(r, hipMalloc(&r->st_s, static_cast<size_t>(n) * CA * sizeof(float)));
-        RP_HIP(r, hipMalloc(&r->st_pi, static_cast<size_t>(n) * r->A * sizeof(double)));
-        RP_HIP(r, hipMalloc(&r->st_z, static_cast<size_t>(n) * sizeof(float)));
-        r->st_n = n;
+        RP_HIP(r, hipMalloc(&r->st_s, static_cast<size_t>(n_st) * CA * sizeof(float)));
+        RP_HIP(r, hipMalloc(&r->st_pi, static_cast<size_t>(n_st) * r->A * sizeof(double)));
+        RP_HIP(r, hipMalloc(&r->st_z, static_cast<size_t>(n_st) * sizeof(float)));
+        r->st_n = n_st;
     }
-    RP_HIP(r, hipMemcpyAsync(r->st_s, states, static_cast<size_t>(n) * CA * sizeof(float), hipMemcpyHostToDevice, s));
-    RP_HIP(r, hipMemcpyAsync(r->st_pi, pi, static_cast<size_t>(n) * r->A * sizeof(double), hipMemcpyHostToDevice, s));
-    RP_HIP(r, hipMemcpyAsync(r->st_z, z, static_cast<size_t>(n) * sizeof(float), hipMemcpyHostToDevice, s));
-    const int64_t total = n * nsym;
-    // entries of this call that are already overwritten by later entries of the same call are skipped
-    const int64_t skip = std::max<int64_t>(0, total - r->cap);
-    const int64_t tail = (r->head + r->count) % r->cap;  // slot of the first new entry
-    const long work = static_cast<long>(total) * (r->C + 1) * r->A;
+    RP_HIP(r, hipMemcpyAsync(r->st_s, states + first_smp * CA, static_cast<size_t>(n_st) * CA * sizeof(float), hipMemcpyHostToDevice, s));
+    RP_HIP(r, hipMemcpyAsync(r->st_pi, pi + first_smp * r->A, static_cast<size_t>(n_st) * r->A * sizeof(double), hipMemcpyHostToDevice, s));
+    RP_HIP(r, hipMemcpyAsync(r->st_z, z + first_smp, static_cast<size_t>(n_st) * sizeof(float), hipMemcpyHostToDevice, s));
+    const int64_t tail = (r->head + r->count + (skipped % r->cap) * nsym) % r->cap;  // slot of the first given entry
+    const long work = static_cast<long>(std::min<int64_t>(total, r->cap + nsym)) * (r->C + 1) * r->A;
     const int block = 256;
     const int grid = static_cast<int>(std::min<long>((work + block - 1) / block, 65535L * 8));
-    (void)skip;  // later writes win: the kernel is launched over all entries in deque order per slot
     if (skip == 0) {
         hipLaunchKernelGGL(ao::k_replay_write, dim3(grid), dim3(block), 0, s, r->st_s, r->st_pi, r->st_z,
                            static_cast<long>(n), nsym, r->s_ring, r->pi_ring, r->z_ring, static_cast<long>(tail),
                            static_cast<long>(r->cap), r->C, r->B);
     } else {
-        // more new entries than slots: write whole samples from the first one that survives at
-        // least partially, one launch per wrap so that no two threads of a launch share a slot
-        const int64_t first_smp = skip / nsym;
+        // more new entries than slots: one launch per wrap so that no two threads of a launch share a slot
         int64_t k0 = first_smp * nsym;
         while (k0 < total) {
             const int64_t smp0 = k0 / nsym;
             const int64_t nsmp = std::min<int64_t>(n - smp0, std::max<int64_t>(1, r->cap / nsym));
-            hipLaunchKernelGGL(ao::k_replay_write, dim3(grid), dim3(block), 0, s, r->st_s + smp0 * CA,
-                               r->st_pi + smp0 * r->A, r->st_z + smp0, static_cast<long>(nsmp), nsym, r->s_ring,
-                               r->pi_ring, r->z_ring, static_cast<long>((tail + k0) % r->cap),
+            hipLaunchKernelGGL(ao::k_replay_write, dim3(grid), dim3(block), 0, s, r->st_s + (smp0 - first_smp) * CA,
+                               r->st_pi + (smp0 - first_smp) * r->A, r->st_z + (smp0 - first_smp), static_cast<long>(nsmp), nsym,
+                               r->s_ring, r->pi_ring, r->z_ring, static_cast<long>((tail + k0) % r->cap),
                                static_cast<long>(r->cap), r->C, r->B);
             k0 += nsmp * nsym;
         }
     }
     RP_HIP(r, hipGetLastError());
     RP_HIP(r, hipStreamSynchronize(s));  // the caller's buffers may go away
-    const int64_t newcount = std::min<int64_t>(r->cap, r->count + total);
-    const int64_t dropped = r->count + total - newcount;
-    r->head = (r->head + dropped) % r->cap;
+    const int64_t logical = (skipped + n) * nsym;
+    const int64_t newcount = std::min<int64_t>(r->cap, r->count + logical);
+    const int64_t dropped = r->count + logical - newcount;
+    r->head = (r->head + dropped % r->cap) % r->cap;
     r->count = newcount;
     return 0;
+}
+
+int ao_replay_extend(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
+                     void* stream) {
+    return extend_impl(r, states, pi, z, n, augment, 0, stream);
+}
+
+int ao_replay_extend_skip(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
+                          int64_t skipped, void* stream) {
+    return extend_impl(r, states, pi, z, n, augment, skipped, stream);
 }
 
 int ao_replay_gather(ao_replay* r, const int64_t* idx, int64_t m, float* dev_states, float* dev_pi, float* dev_z,

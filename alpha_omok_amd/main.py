@@ -67,13 +67,24 @@ _engine = None
 _evaluator = None
 _episodes_played = 0
 _trim_seen = [0]
+_trim_base = [0, 0]          # counters of engines that were closed since configure()
+STRICT = False               # configure(strict=True): an arena trim raises TreeTrimmed instead of logging a warning
+NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 4*(sims+1); -1: grow into the free HBM)
+trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
-              model=None, gpu=None, noise=True, device_replay=False):
-    """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants."""
+              model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None):
+    """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
+    node_cap: expanded-node capacity of a game's tree arena (0 = 4*(n_mcts+1), -1 = grow into the free HBM);
+    strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
+    logged and `trim_stats` / self_play's return value carry the counters)."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
-    global _engine, _evaluator, _episodes_played, rep_memory
+    global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP
+    STRICT = STRICT if strict is None else bool(strict)
+    NODE_CAP = NODE_CAP if node_cap is None else int(node_cap)
+    _trim_base[0] = _trim_base[1] = 0
+    trim_stats['subtrees_dropped'] = trim_stats['reroots_trimmed'] = 0
     import torch
     from .pvnet import PVNet
     BOARD_SIZE = board_size or BOARD_SIZE
@@ -110,9 +121,12 @@ def _get_engine(games):
     global _engine
     if _engine is None or _engine.G != games:
         if _engine is not None:
+            d, t = _engine.trim_stats()
+            _trim_base[0] += d
+            _trim_base[1] += t
             _engine.close()
         _trim_seen[0] = 0
-        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device)
+        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device, node_cap=NODE_CAP)
     return _engine
 
 
@@ -124,62 +138,88 @@ def release_engine():
         _engine = None
 
 
+class TreeTrimmed(RuntimeError):
+    """strict=True: re-rooting had to forget subtrees because a game's kept tree outgrew node_cap (the reference's
+    dict never forgets, agents.py:52), so the searches of those games no longer follow the reference."""
+
+
+def _check_trim(eng):
+    dropped, trimmed = eng.trim_stats()
+    trim_stats['subtrees_dropped'] = _trim_base[0] + dropped
+    trim_stats['reroots_trimmed'] = _trim_base[1] + trimmed
+    if trimmed > _trim_seen[0]:
+        msg = ('tree arenas full in {} re-rootings so far ({} child subtrees forgotten; node_cap {}): the searches of those '
+               'games diverge from the reference, raise node_cap'.format(trimmed, dropped, eng.node_cap()[0]))
+        _trim_seen[0] = trimmed
+        if STRICT:
+            raise TreeTrimmed(msg)
+        logging.warning(msg)
+
+
 def _play_episodes(episodes, use_global, seed_of):
     """Plays the listed episodes on one engine (G = min(len, MAX_CONCURRENT) slots, finished slots refilled).
-    Returns ({episode: moves}, {episode: [pi per ply]}, {episode: win_index})."""
-    G = min(len(episodes), MAX_CONCURRENT)
+    Returns (moves [E, A] int32 (-1 padded), lengths [E], wins [E], pis: list of [length_e, A] float64 per episode),
+    E = len(episodes), rows in the order of `episodes`. Per ply the host only touches whole [G]-arrays; the games
+    that finished in that ply are the only per-game work."""
+    E = len(episodes)
+    A = BOARD_SIZE * BOARD_SIZE
+    G = min(E, MAX_CONCURRENT)
     eng = _get_engine(G)
     eng.reset()
-    slot_ep = np.full(G, -1, np.int64)
-    queue = list(episodes)
-    moves = {}
-    pis = {}
-    wins = {}
+    slot_row = np.full(G, -1, np.int64)                   # row (position in `episodes`) played on each slot
+    next_row = 0
+    lengths = np.zeros(E, np.int64)
+    wins = np.zeros(E, np.int64)
+    moves = np.full((E, A), -1, np.int32)
     for g in range(G):
-        ep = queue.pop(0)
-        slot_ep[g] = ep
-        moves[ep], pis[ep] = [], []
+        slot_row[g] = next_row
         if use_global:
             st = np.random.get_state()
             eng.set_rng_state(g, st[1], st[2], st[3], st[4])
         else:
-            eng.seed(g, seed_of(ep))
+            eng.seed(g, seed_of(episodes[next_row]))
+        next_row += 1
     active = np.ones(G, np.uint8)
+    ply = np.zeros(G, np.int64)
+    hist = []                                             # per search: (rows [n], plies [n], pi [n, A]) of the active slots
     while active.any():
-        ply = np.array([len(moves[e]) if e >= 0 else 0 for e in slot_ep])
-        tau = (ply < TAU_THRES).astype(np.int8)          # main.py:150-153
+        tau = (ply < TAU_THRES).astype(np.int8)           # main.py:150-153
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
         act, win = eng.play()                             # utils.get_action + env.step
-        refill = np.zeros(G, np.uint8)
-        waiting = len(queue)                              # episodes still without a slot
-        for g in np.nonzero(active)[0]:
-            ep = int(slot_ep[g])
-            pis[ep].append(pi[g].copy())
-            moves[ep].append(int(act[g]))
-            if win[g] != 0:
-                wins[ep] = int(win[g])
-                if waiting > 0:
+        on = np.flatnonzero(active)
+        rows = slot_row[on]
+        hist.append((rows, ply[on].copy(), pi[on]))
+        moves[rows, ply[on]] = act[on]
+        ply[on] += 1
+        done = on[win[on] != 0]
+        if done.size:
+            r = slot_row[done]
+            lengths[r] = ply[done]
+            wins[r] = win[done]
+            refill = np.zeros(G, np.uint8)
+            for g in done:                                # finished games only
+                if next_row < E:
                     refill[g] = 1
-                    waiting -= 1
+                    slot_row[g] = next_row
+                    next_row += 1
                 else:
                     active[g] = 0
-                    slot_ep[g] = -1
-        if refill.any():
-            eng.reset(refill)                             # Agent.reset() (main.py:248)
-            for g in np.nonzero(refill)[0]:
-                ep = queue.pop(0)
-                slot_ep[g] = ep
-                moves[ep], pis[ep] = [], []
-                eng.seed(int(g), seed_of(ep))
-    dropped, trimmed = eng.trim_stats()
-    if trimmed > _trim_seen[0]:
-        logging.warning('tree arenas full in {} re-rootings so far ({} child subtrees forgotten): raise node_cap'.format(
-            trimmed, dropped))
-        _trim_seen[0] = trimmed
+                    slot_row[g] = -1
+                ply[g] = 0
+            if refill.any():
+                eng.reset(refill)                         # Agent.reset() (main.py:248)
+                for g in np.flatnonzero(refill):
+                    eng.seed(int(g), seed_of(episodes[slot_row[g]]))
+    _check_trim(eng)
     if use_global:
         mt, pos, hg, gs = eng.get_rng_state(0)
         np.random.set_state(('MT19937', mt, pos, hg, gs))
-    return moves, pis, wins
+    # pi rows per episode in ply order: one stable sort over all searches instead of a Python append per game and ply
+    rows = np.concatenate([h[0] for h in hist])
+    plies = np.concatenate([h[1] for h in hist])
+    pis = np.concatenate([h[2] for h in hist])
+    order = np.lexsort((plies, rows))
+    return moves, lengths, wins, rows[order], plies[order], pis[order]
 
 
 def self_play(n_selfplay, seeds=None, single_stream=False):
@@ -189,7 +229,10 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     single_stream=True is the reference's own schedule for n_selfplay > 1 (main.py:136-142): the episodes are
     played ONE AFTER ANOTHER and all draw from the process-global np.random stream, so
     `np.random.seed(s); self_play(n, single_stream=True)` reproduces the reference's memory bit for bit (gv9) --
-    at one game's speed. The default plays the episodes side by side with per-episode streams."""
+    at one game's speed. The default plays the episodes side by side with per-episode streams.
+
+    Returns a summary dict (the reference returns None): episodes and move decisions of this rank, and the
+    cumulative arena-trim counters (`trim_stats`; with configure(strict=True) a trim raises TreeTrimmed)."""
     global _episodes_played
     if Agent is None:
         configure()
@@ -203,41 +246,46 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     _episodes_played += n_selfplay                        # identical on every rank, shard or no shard
     if not episodes:
         Agent.reset()
-        return
+        return dict(episodes=0, moves=0, **trim_stats)
 
     def seed_of(ep):
         return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
 
+    A = BOARD_SIZE * BOARD_SIZE
     if single_stream or (n_selfplay == 1 and seeds is None and world == 1):
-        moves, pis, wins = {}, {}, {}
-        for ep in episodes:                               # sequential, each on the global stream where the last left it
-            m, p, w = _play_episodes([ep], True, seed_of)
-            moves.update(m); pis.update(p); wins.update(w)
+        parts = [_play_episodes([ep], True, seed_of) for ep in episodes]   # sequential, each on the global stream where the last left it
+        moves = np.concatenate([p[0] for p in parts])
+        lengths = np.concatenate([p[1] for p in parts])
+        wins = np.concatenate([p[2] for p in parts])
+        ep_of = np.concatenate([np.full(p[3].shape[0], i, np.int64) for i, p in enumerate(parts)])
+        ply_of = np.concatenate([p[4] for p in parts])
+        pis = np.concatenate([p[5] for p in parts])
     else:
-        moves, pis, wins = _play_episodes(episodes, False, seed_of)
+        moves, lengths, wins, ep_of, ply_of, pis = _play_episodes(episodes, False, seed_of)
 
-    # results and samples in episode order (main.py:201-227)
-    for ep in episodes:
-        w = wins[ep]
-        if w == 1:
-            reward_black, reward_white = 1., -1.
-            result['Black'] += 1
-        elif w == 2:
-            reward_black, reward_white = -1., 1.
-            result['White'] += 1
-        else:
-            reward_black, reward_white = 0., 0.
-            result['Draw'] += 1
-        root = (0,)
-        for t, (a, p) in enumerate(zip(moves[ep], pis[ep])):
-            state = utils.get_state_pt(root, BOARD_SIZE, IN_PLANES)
-            cur_memory.append((state, p, reward_black if t % 2 == 0 else reward_white))
-            root = root + (a,)
+    # results and samples in episode order (main.py:201-227); samples arrive sorted by (episode, ply)
+    result['Black'] += int((wins == 1).sum())
+    result['White'] += int((wins == 2).sum())
+    result['Draw'] += int(((wins != 1) & (wins != 2)).sum())
+    reward_black = np.where(wins == 1, 1., np.where(wins == 2, -1., 0.))
+    z = np.where(ply_of % 2 == 0, reward_black[ep_of], -reward_black[ep_of])
+    z = np.where(z == 0, 0., z)                           # (no -0.0: the reference's draw reward is +0.0 for both colours)
+    states = utils.states_of_episodes(moves, lengths, ep_of, ply_of, BOARD_SIZE, IN_PLANES)
+    n_new = states.shape[0]
+    zl = z.tolist()
+    cur_memory.extend(zip(states, pis, zl))               # rows of the big arrays: (state f64 [C,B,B], pi f64 [A], z float)
     Agent.reset()
-    if hasattr(rep_memory, "extend_augmented"):
-        rep_memory.extend_augmented(cur_memory)           # symmetries made on the device
+    if hasattr(rep_memory, "extend_augmented_arrays"):
+        rep_memory.extend_augmented_arrays(states, pis, z)   # symmetries made on the device; only what can survive is uploaded
     else:
-        rep_memory.extend(utils.augment_dataset(cur_memory, BOARD_SIZE))
+        # deque(maxlen) keeps the newest entries only: once this call alone fills it, just the samples whose
+        # symmetries can survive are augmented (identical final content, without 8 x n_new Python tuples)
+        keep = n_new
+        if rep_memory.maxlen is not None and 8 * n_new >= rep_memory.maxlen:
+            keep = min(n_new, -(-rep_memory.maxlen // 8))
+        tail = [(states[i], pis[i], zl[i]) for i in range(n_new - keep, n_new)]
+        rep_memory.extend(utils.augment_dataset(tail, BOARD_SIZE))
+    return dict(episodes=len(episodes), moves=int(n_new), **trim_stats)
 
 
 def train_batch(batch):

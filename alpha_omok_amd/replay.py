@@ -62,6 +62,29 @@ class DeviceReplay:
         """rep_memory.extend(utils.augment_dataset(samples, board_size)) with the symmetries made on the device."""
         self._push(samples, True)
 
+    def extend_augmented_arrays(self, states, pi, z):
+        """extend_augmented for samples that already are arrays (states [n,C,B,B], pi [n,A], z [n], any float type):
+        no per-sample Python objects, and only the samples whose symmetries can survive in the memory are converted
+        and uploaded (the rest of the call just moves the ring position, ao_replay_extend_skip)."""
+        n = int(states.shape[0])
+        if n == 0:
+            return
+        if tuple(states.shape[1:]) != (self.C, self.B, self.B) or tuple(pi.shape[1:]) != (self.A,):
+            raise ReplayError("sample shapes %r / %r do not match the memory" % (states.shape[1:], pi.shape[1:]))
+        cap = self.maxlen
+        first = 0
+        if 8 * n > cap:
+            first = max(0, n - (-(-cap // 8) + 1))
+            if 8 * (n - first) < cap:
+                first = 0
+        s = np.ascontiguousarray(states[first:], dtype=np.float32)
+        p = np.ascontiguousarray(pi[first:], dtype=np.float64)
+        zz = np.ascontiguousarray(z[first:], dtype=np.float32)
+        self._check(self._L.ao_replay_extend_skip(self._h, s.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  p.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  zz.ctypes.data_as(C.POINTER(C.c_float)), n - first, 1, first, None),
+                    "ao_replay_extend_skip")
+
     def read(self, first, n):
         s = np.empty((n, self.C, self.B, self.B), np.float64)
         pi = np.empty((n, self.A), np.float64)

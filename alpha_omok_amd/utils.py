@@ -67,6 +67,37 @@ def get_state_pt(node_id, board_size, channel_size):
     return planes.reshape(channel_size, board_size, board_size)
 
 
+def states_of_episodes(moves, lengths, ep_of, ply_of, board_size, channel_size, dtype=np.float64):
+    """get_state_pt for MANY positions at once: sample i is the root (0, m_1, ..., m_t) of episode ep_of[i] after
+    t = ply_of[i] of its moves (moves [E, L] int, -1 padded; lengths [E]). Returns [N, C, B, B] of `dtype`, equal
+    entry for entry to np.stack([get_state_pt(...)]) (utils.py:139-168) -- cumulative stone sets per colour, then
+    one gather per history plane instead of a Python call per sample."""
+    moves = np.asarray(moves, dtype=np.int64)
+    ep_of = np.asarray(ep_of, dtype=np.int64)
+    ply_of = np.asarray(ply_of, dtype=np.int64)
+    E, L = moves.shape
+    A = board_size * board_size
+    N = ep_of.shape[0]
+    # cum[c, e, j] = stones of colour c (0 black: even move index) after the first j+1 moves of episode e
+    onehot = np.zeros((E, L, A), np.uint8)
+    ee, jj = np.nonzero(moves >= 0)
+    onehot[ee, jj, moves[ee, jj]] = 1
+    cum = np.zeros((2, E, L, A), np.uint8)
+    par = (np.arange(L) % 2)[None, :, None]
+    cum[0] = np.cumsum(onehot * (par == 0), axis=1, dtype=np.uint8)
+    cum[1] = np.cumsum(onehot * (par == 1), axis=1, dtype=np.uint8)
+    out = np.zeros((N, channel_size, A), dtype)
+    for j in range(channel_size - 1):
+        p = ply_of - j                        # X_p: the mover of (1-based) ply p after that ply; black moves the odd plies
+        ok = p >= 1
+        idx = np.flatnonzero(ok)
+        if idx.size:
+            pp = p[idx]
+            out[idx, channel_size - 2 - j] = cum[(pp - 1) % 2, ep_of[idx], pp - 1]
+    out[:, channel_size - 1, :] = (ply_of % 2 == 0).astype(dtype)[:, None]
+    return out.reshape(N, channel_size, board_size, board_size)
+
+
 def get_action(pi):
     """Sample the played move from np.random (utils.py:189-195). Returns (one-hot, index)."""
     n = len(pi)

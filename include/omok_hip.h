@@ -213,6 +213,11 @@ int  ao_replay_clear(ao_replay *r);
  * left-right flip), computed on the device; augment == 0 appends the samples as they are. */
 int  ao_replay_extend(ao_replay *r, const float *states, const double *pi, const float *z, int64_t n,
                       int augment, void *stream);
+/* the same for a call whose first `skipped` samples are NOT supplied: main.self_play(n) appends every sample of its n
+ * games (main.py:229-231), but a deque(maxlen) keeps the newest entries only -- when the supplied n samples alone fill
+ * the memory (n * 8 >= capacity with augment), the earlier ones of the same call only move the ring position. */
+int  ao_replay_extend_skip(ao_replay *r, const float *states, const double *pi, const float *z, int64_t n,
+                           int augment, int64_t skipped, void *stream);
 /* Mini-batch for m deque indices (host int64; e.g. random.sample(range(len), m)): writes float32
  * device buffers states [m][C][B][B], pi [m][A], z [m] -- the tensors main.train feeds the net. */
 int  ao_replay_gather(ao_replay *r, const int64_t *idx, int64_t m, float *dev_states, float *dev_pi,

@@ -143,6 +143,29 @@ def test_self_play_concurrent_episodes_match_oracle_games(oracle):
     assert len(main.rep_memory) == min(8 * len(cm), main.MEMORY_SIZE)
 
 
+def test_self_play_reports_arena_trims_and_strict_mode_raises(oracle):
+    """A tree arena too small for what the searches keep from move to move makes re-rooting forget subtrees -- a
+    divergence from the reference's never-pruned dict (agents.py:52) that must not pass silently: self_play returns /
+    main.trim_stats carry the counters, configure(strict=True) raises; a roomy arena reports zeros."""
+    import alpha_omok_amd.main as main
+    B, S = 9, 60
+    main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, 1), seed=5, node_cap=S + 2, strict=False)
+    main.cur_memory.clear()
+    main.rep_memory.clear()
+    out = main.self_play(3)
+    assert out["episodes"] == 3 and out["moves"] == len(main.cur_memory)
+    assert out["reroots_trimmed"] > 0 and out["subtrees_dropped"] > 0 and main.trim_stats["reroots_trimmed"] == out["reroots_trimmed"]
+    main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, 1), seed=5, node_cap=S + 2, strict=True)
+    with pytest.raises(main.TreeTrimmed):
+        main.self_play(3)
+    main.configure(board_size=B, n_mcts=S, model=StubModel(oracle, 1), seed=5, node_cap=0, strict=True)
+    main.cur_memory.clear()
+    out = main.self_play(3)
+    assert out["reroots_trimmed"] == 0 and out["subtrees_dropped"] == 0
+    main.configure(node_cap=0, strict=False)
+    main.release_engine()
+
+
 def test_head_to_head_two_agents_match_oracle(oracle):
     """eval_main's call pattern: two ZeroAgents (noise off, tau 0) alternate on one game, each
     re-rooting two plies down after the opponent's reply -- against two oracle agents fed the same way."""

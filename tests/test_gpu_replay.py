@@ -76,6 +76,26 @@ def test_ring_matches_deque_through_wraps(board, cap):
     mem.close()
 
 
+@pytest.mark.parametrize("board,cap,n", [(9, 100, 40), (9, 96, 12), (9, 97, 13), (3, 30000, 5000), (15, 37, 9), (9, 1000, 20)])
+def test_extend_augmented_arrays_uploads_only_what_survives(board, cap, n):
+    """main.self_play hands its samples over as arrays; when they alone fill the memory only the newest are uploaded
+    (ao_replay_extend_skip) -- contents, order and length == deque(maxlen).extend(augment(all of them)), also on top
+    of older entries and followed by more."""
+    from alpha_omok_amd import utils
+    from alpha_omok_amd.replay import DeviceReplay
+    rs = np.random.RandomState(cap + n)
+    mem = DeviceReplay(board, 5, cap)
+    ref = deque(maxlen=cap)
+    for k in (3, n, 2, n):
+        smp = _samples(rs, k, board)
+        mem.extend_augmented_arrays(np.stack([m[0] for m in smp]), np.stack([m[1] for m in smp]), np.array([m[2] for m in smp]))
+        ref.extend(utils.augment_dataset(smp, board))
+        assert len(mem) == len(ref)
+        _same(list(mem)[-50:], list(ref)[-50:])
+        _same(list(mem)[:20], list(ref)[:20])
+    mem.close()
+
+
 def test_batches_match_host_assembly():
     """batch(indices) == torch.tensor(np.stack(...)).float() of the same deque entries (main.py:283-290)."""
     import torch

@@ -113,6 +113,12 @@ def test_golden_gv5_deep_roots(oracle):
     _run_golden_cases(oracle, g, lambda ci, mode: (lambda gi, sim, pl: oracle.stub_eval(pl, mode)))
 
 
+def test_golden_gv5_deep_roots_15x15(oracle):
+    """Roots with 150 / 152 / 160 stones on 15x15: the 128-slot-table case of the child order on the device."""
+    g = load_golden("gv5_tree_stub_deeproot15")
+    _run_golden_cases(oracle, g, lambda ci, mode: (lambda gi, sim, pl: oracle.stub_eval(pl, mode)))
+
+
 def test_golden_gv6_real_net_replay():
     """Search driven by the reference PVNet's recorded (p, v): same visits and moves."""
     g = load_golden("gv6_tree_realnet")
@@ -280,8 +286,11 @@ def test_set_root_semantics(oracle):
 @pytest.mark.parametrize("B,S,G,blocks", [(9, 400, 4096, 4), (15, 800, 1024, 10)])
 def test_full_size_properties_and_sampled_oracle_parity(oracle, B, S, G, blocks):
     """BASELINE configs[2] size (9x9, 4096 games x 400 sims, 4-block net, group-resident trunk) and the per-GPU
-    shape of configs[4] (15x15, 800 sims, 10-block net, all 1024 games of one GPU):
-    size-independent properties for every game + bit-exact oracle replay of a few sampled games."""
+    shape of configs[4] (15x15, 800 sims, 10-block net, all 1024 games of one GPU), FOUR plies with re-rooting
+    (eng.play) between them -- tau = 1, 1, 0, 0 (arg-max + tie-break stream) -- and a refill before the fourth (a
+    handful of slots reset and re-seeded, so fresh roots with S + 1 simulations search beside inherited ones):
+    size-independent properties for every game at every ply + bit-exact oracle replay of the sampled games
+    (visits, post-noise priors, pi, chosen action, MT19937 position and state) at every ply."""
     import torch
     import pvnet_weights
     from alpha_omok_amd.engine import Engine, Net
@@ -294,57 +303,100 @@ def test_full_size_properties_and_sampled_oracle_parity(oracle, B, S, G, blocks)
         model = PVNet(blocks, 5, 128, B)
         model.eval()
         net = model.to_native(0)
+    A = B * B
     eng = Engine(B, S, 5, games=G, noise=True)
     seeds = np.arange(9000, 9000 + G, dtype=np.uint32)
     eng.seed_all(seeds)
     sample = [0, 1, 17, G // 2, G - 1]
+    refill = [1, 5, 6, G - 2]                                # game 1 is sampled: its oracle restarts too
     planes = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
-    rec = {g: [] for g in sample}
-    eng.begin_move()
-    while eng.sims_left() > 0:
-        eng.collect_leaves(planes.data_ptr())
-        eng.sync()
-        p, v = net(planes)                       # ao_net_forward: same kernels as ao_search
-        torch.cuda.synchronize()
-        hp, hv = p[sample].cpu().numpy(), v[sample].cpu().numpy()
-        for i, g in enumerate(sample):
-            rec[g].append((hp[i].copy(), hv[i].copy()))
-        eng.apply_evals(p.data_ptr(), v.data_ptr())
-    tau = np.ones(G, np.int8)
-    pi, vis, pol = eng.end_move(tau)
-    # properties that hold for every game regardless of size
-    assert np.all(vis.sum(axis=1) == S)                      # fresh root: S+1 sims, S child visits
-    assert np.all(vis == np.round(vis)) and np.all(vis >= 0)
-    assert np.abs(pi.sum(axis=1) - 1).max() < 1e-12
-    assert np.abs(pol.sum(axis=1) - 1).max() < 1e-9          # renormalised priors mixed with Dirichlet noise
-    assert np.all(pol > 0)                                   # every cell is legal on the empty board
-    st = eng.search_stats()
-    assert st["evaluated"] + st["terminal"] == G * (S + 1) and st["terminal"] == 0
-    assert 1.0 < st["levels"] / (G * (S + 1)) < 4.0
-    act, win = eng.play()
-    assert np.all(win == 0) and np.all((act >= 0) & (act < B * B))
-    assert np.all(vis[np.arange(G), act] > 0)                # the sampled move was visited
-    # sampled games against the oracle, bit for bit
-    for g in sample:
-        cur = [0]
+    cursors = {g: [0] for g in sample}
+    recs = {g: [] for g in sample}
 
-        def replay(moves, pl, sim, g=g, cur=cur):
-            i = cur[0]
-            cur[0] += 1
-            return rec[g][i]
-
+    def make_agent(g, seed):
+        def replay(moves, pl, sim, g=g):
+            i = cursors[g][0]
+            cursors[g][0] += 1
+            return recs[g][i]
         ag = oracle.Agent(B, S, 5, noise=True, evaluator=replay)
-        ag.seed(int(seeds[g]))
-        opi, ovis, opol = ag.get_pi((0,), 1)
-        np.testing.assert_array_equal(vis[g], ovis, err_msg="game %d" % g)
-        np.testing.assert_array_equal(pol[g], opol)
-        assert act[g] == ag.rng.choice_p(opi)
-    # determinism: a second engine with the same seeds and the fused path gives the same visits
+        ag.seed(int(seed))
+        return ag
+
+    agents = {g: make_agent(g, seeds[g]) for g in sample}
+    roots = {g: (0,) for g in sample}
+    ply = np.zeros(G, np.int64)
+    inherited = np.zeros(G)                                  # visits the root's children hold before the search
+    first_vis = None
+    for t in range(4):
+        if t == 3:
+            mask = np.zeros(G, np.uint8)
+            mask[refill] = 1
+            eng.reset(mask)
+            for k, g in enumerate(refill):
+                eng.seed(g, 50000 + k)
+            ply[refill] = 0
+            inherited[refill] = 0
+            agents[1] = make_agent(1, 50000)
+            roots[1] = (0,)
+        tau = (ply < 2).astype(np.int8)
+        fresh = ply == 0
+        for g in sample:
+            recs[g] = []
+            cursors[g][0] = 0
+        eng.begin_move()
+        assert eng.sims_left() == (S + 1 if fresh.any() else S)
+        while eng.sims_left() > 0:
+            eng.collect_leaves(planes.data_ptr())
+            eng.sync()
+            p, v = net(planes)                       # ao_net_forward: same kernels as ao_search
+            torch.cuda.synchronize()
+            hp, hv = p[sample].cpu().numpy(), v[sample].cpu().numpy()
+            for i, g in enumerate(sample):
+                recs[g].append((hp[i].copy(), hv[i].copy()))
+            eng.apply_evals(p.data_ptr(), v.data_ptr())
+        pi, vis, pol = eng.end_move(tau)
+        if t == 0:
+            first_vis, first_pol = vis.copy(), pol.copy()
+        # properties that hold for every game regardless of size
+        np.testing.assert_array_equal(vis.sum(axis=1), inherited + S)   # fresh root: S+1 sims, S child visits; else on top of the inherited ones
+        assert np.all(vis == np.round(vis)) and np.all(vis >= 0)
+        assert np.abs(pi.sum(axis=1) - 1).max() < 1e-12
+        assert np.abs(pol.sum(axis=1) - 1).max() < 1e-9          # renormalised priors mixed with Dirichlet noise
+        npos = (pol > 0).sum(axis=1)                             # the legal cells carry a prior (a Dirichlet component may underflow)
+        assert np.all(npos <= A - ply) and np.all(npos >= A - ply - 1)
+        onehot = tau == 0
+        assert np.all(pi[onehot].max(axis=1) == 1.0) and np.all((pi[onehot] > 0).sum(axis=1) == 1)
+        assert np.all(vis[onehot, pi[onehot].argmax(axis=1)] == vis[onehot].max(axis=1))   # the arg-max is a maximum
+        st = eng.search_stats()
+        assert st["evaluated"] + st["terminal"] == int((S + fresh).sum()) and st["terminal"] == 0
+        assert 1.0 < st["levels"] / st["evaluated"] < 4.0
+        act, win = eng.play()
+        assert np.all(win == 0) and np.all((act >= 0) & (act < A))
+        assert np.all(vis[np.arange(G), act] > 0)                # the chosen move was visited
+        assert np.all(act[onehot] == pi[onehot].argmax(axis=1))
+        # sampled games against the oracle, bit for bit
+        for g in sample:
+            tag = "game %d ply %d (search %d)" % (g, ply[g], t)
+            opi, ovis, opol = agents[g].get_pi(roots[g], int(tau[g]))
+            assert cursors[g][0] == S + (1 if ply[g] == 0 else 0), tag
+            np.testing.assert_array_equal(vis[g], ovis, err_msg=tag)
+            np.testing.assert_array_equal(pol[g], opol, err_msg=tag)
+            np.testing.assert_array_equal(pi[g], opi, err_msg=tag)
+            oa = agents[g].rng.choice_p(opi)
+            assert act[g] == oa, tag
+            roots[g] = roots[g] + (int(oa),)
+            mt, pos, _, _ = eng.get_rng_state(g)
+            assert pos == agents[g].rng.pos, tag
+            np.testing.assert_array_equal(mt, agents[g].rng.state_words(), err_msg="mt " + tag)
+        inherited = vis[np.arange(G), act] - 1                   # the chosen child's own first visit expanded it
+        ply += 1
+    assert eng.trim_stats() == (0, 0)                            # nothing was forgotten at re-rooting
+    # determinism: a second engine with the same seeds and the fused path gives the same first move
     eng2 = Engine(B, S, 5, games=G, noise=True)
     eng2.seed_all(seeds)
-    pi2, vis2, pol2 = eng2.search(net, tau=tau)
-    np.testing.assert_array_equal(vis2, vis)
-    np.testing.assert_array_equal(pol2, pol)
+    pi2, vis2, pol2 = eng2.search(net, tau=np.ones(G, np.int8))
+    np.testing.assert_array_equal(vis2, first_vis)
+    np.testing.assert_array_equal(pol2, first_pol)
     eng.close()
     eng2.close()
     net.close()

@@ -126,6 +126,17 @@ def test_gv5_tree_parity_deep_roots(oracle):
     assert nonasc >= 1
 
 
+def test_gv5_tree_parity_deep_roots_15x15(oracle):
+    """15x15 roots with 150 / 152 / 160 stones (>= 149: CPython's set difference ends in a 128-slot table smaller
+    than the largest key, SURVEY Q5 / utils.py:22-27): every root lists its children in non-ascending order."""
+    g = load_golden("gv5_tree_stub_deeproot15")
+    _check_tree_cases(oracle, g, lambda ci, mode: "stub%d" % mode)
+    for ci in range(len(g["meta"])):
+        o = g["c%d_order" % ci][0]
+        o = o[o >= 0].tolist()
+        assert o != sorted(o) and int(g["c%d_root" % ci][0].shape[0]) >= 150
+
+
 def test_gv6_tree_parity_real_net_replay(oracle):
     g = load_golden("gv6_tree_realnet")
     ep, ev = g["eval_p"], g["eval_v"]

@@ -305,6 +305,34 @@ def gv5():
     out = _pack(cases)
     save("gv5_tree_stub_deeproot", **out)
 
+    # searches from deep 15x15 roots (>= 149 stones: the 128-slot table case of CPython's set difference).
+    # A random 152-stone position on 15x15 almost surely holds a five, so the stones are drawn from a five-free
+    # colouring of the whole board (runs of two along rows, alternating along columns; checked with the reference's
+    # check_win): any subset of a five-free position is five-free.
+    B15 = 15
+    full = np.zeros((B15, B15), np.int64)
+    for r in range(B15):
+        for c in range(B15):
+            full[r, c] = 1 if ((c // 2) + r) % 2 == 0 else -1
+    assert ref_utils.check_win(full.astype(float), 5) in (0, 3), "the colouring holds a five"
+    black = [r * B15 + c for r in range(B15) for c in range(B15) if full[r, c] == 1]
+    white = [r * B15 + c for r in range(B15) for c in range(B15) if full[r, c] == -1]
+    rng = np.random.RandomState(77)
+    cases = []
+    for k, n_stones in enumerate((150, 152, 160)):
+        bsel = rng.permutation(black)[:n_stones // 2].tolist()
+        wsel = rng.permutation(white)[:n_stones // 2].tolist()
+        mv = [x for pair in zip(bsel, wsel) for x in pair]       # black moves first (utils.get_board: even index = +1)
+        nid = (0,) + tuple(mv)
+        assert ref_utils.check_win(ref_utils.get_board(nid, B15), 5) == 0
+        legal = ref_utils.legal_actions(nid, B15)
+        assert legal != sorted(legal), "expected a non-ascending child order at %d stones" % n_stones
+        recs, win = _play(B15, 40, k % 3, 200 + k, 2, start=nid)
+        cases.append(((B15, 40, k % 3, 200 + k, 2, 6, 1), recs, win))
+        print("  gv5 deep 15x15 root,", n_stones, "stones ->", len(recs), "plies, win", win)
+    out = _pack(cases)
+    save("gv5_tree_stub_deeproot15", **out)
+
 
 def gv6():
     torch.manual_seed(0)
