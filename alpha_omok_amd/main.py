@@ -22,7 +22,9 @@ Differences by design:
     entries, their order and the batches drawn under a given `random` state are the reference's.
 """
 import logging
+import os
 import random
+import time
 from collections import deque
 
 import numpy as np
@@ -70,6 +72,7 @@ _trim_seen = [0]
 _trim_base = [0, 0]          # counters of engines that were closed since configure()
 STRICT = False               # configure(strict=True): an arena trim raises TreeTrimmed instead of logging a warning
 NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 4*(sims+1); -1: grow into the free HBM)
+last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of every search of the last _play_episodes call
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 
 
@@ -182,10 +185,14 @@ def _play_episodes(episodes, use_global, seed_of):
     active = np.ones(G, np.uint8)
     ply = np.zeros(G, np.int64)
     hist = []                                             # per search: (rows [n], plies [n], pi [n, A]) of the active slots
+    trace = [] if os.environ.get("AO_SELFPLAY_TRACE") else None   # (active games, seconds) per search, for tools/time_self_play.py
     while active.any():
         tau = (ply < TAU_THRES).astype(np.int8)           # main.py:150-153
+        t_search = time.perf_counter()
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
         act, win = eng.play()                             # utils.get_action + env.step
+        if trace is not None:
+            trace.append((int(active.sum()), time.perf_counter() - t_search))
         on = np.flatnonzero(active)
         rows = slot_row[on]
         hist.append((rows, ply[on].copy(), pi[on]))
@@ -211,6 +218,8 @@ def _play_episodes(episodes, use_global, seed_of):
                 for g in np.flatnonzero(refill):
                     eng.seed(int(g), seed_of(episodes[slot_row[g]]))
     _check_trim(eng)
+    if trace is not None:
+        last_trace[:] = trace
     if use_global:
         mt, pos, hg, gs = eng.get_rng_state(0)
         np.random.set_state(('MT19937', mt, pos, hg, gs))

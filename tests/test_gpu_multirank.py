@@ -19,7 +19,7 @@ B, S, NB, EPISODES = 9, 24, 2, 6
 
 def _run(n_episodes):
     from alpha_omok_amd import main
-    main.configure(board_size=B, n_mcts=S, n_blocks=NB, seed=7, gpu=0)
+    main.configure(board_size=B, n_mcts=S, n_blocks=NB, in_planes=5, out_planes=128, seed=7, gpu=0, node_cap=0, strict=False)   # (every knob: other tests leave theirs in the module)
     main.cur_memory.clear()
     main.self_play(n_episodes)
     return [(np.asarray(s, np.float64), np.asarray(p, np.float64), float(z)) for s, p, z in main.cur_memory]

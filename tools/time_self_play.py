@@ -11,9 +11,21 @@ dr = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 main.configure(board_size=9, n_mcts=sims, n_blocks=nb, seed=0, device_replay=dr)
 main.self_play(min(n, 64))            # warm-up: builds the engine, exports the net
 main.cur_memory.clear(); main.rep_memory.clear()
+os.environ["AO_SELFPLAY_TRACE"] = "1"
 t0 = time.perf_counter()
 main.self_play(n)
 dt = time.perf_counter() - t0
 moves = len(main.cur_memory)
 print("self_play(%d) @%d sims, %d blocks, device_replay=%s: %.1f s, %d move decisions = %.0f move-decisions/s, "
       "%d replay entries" % (n, sims, nb, dr, dt, moves, moves / dt, len(main.rep_memory)))
+
+tr = main.last_trace
+if tr:
+    ts = sum(t for _, t in tr)
+    print("searches: %d, %.1f s inside search+play (%.1f s outside: sample assembly, augmentation, bookkeeping)" % (len(tr), ts, dt - ts))
+    for lo, hi in ((3072, 1 << 30), (1024, 3072), (256, 1024), (48, 256), (0, 48)):
+        sel = [(a, t) for a, t in tr if lo <= a < hi]
+        if sel:
+            print("  active games in [%d, %s): %3d searches, %6.2f s, %7d move decisions, %.0f move-decisions/s" % (
+                lo, "inf" if hi > 1 << 20 else hi, len(sel), sum(t for _, t in sel), sum(a for a, _ in sel),
+                sum(a for a, _ in sel) / sum(t for _, t in sel)))
