@@ -20,9 +20,19 @@ class Evaluator:
         self._cfg = None
         self._net = None
         self._bufs = None
+        self._warned_width = False
 
     def native_net(self, model, board_size, inplanes):
         cfg = pvnet.looks_like_pvnet(model)
+        if cfg is not None and (cfg[2] % 32 or cfg[2] > 128) and cfg[3] == board_size and cfg[1] == inplanes:
+            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward is built for 32 / 64 / 96 / 128
+            if not self._warned_width:
+                import warnings
+                warnings.warn("PVNet with %d planes: the native MI355X forward covers 32, 64, 96 and 128 planes -- this network "
+                              "is evaluated by its own torch module, one call per simulation on the whole leaf batch "
+                              "(correct, but several times slower than the MFMA kernels)" % cfg[2], RuntimeWarning, stacklevel=3)
+                self._warned_width = True
+            return None
         if cfg is None or cfg[2] % 32 or cfg[2] > 128 or cfg[3] != board_size or cfg[1] != inplanes:
             return None
         # the native copy is keyed on the module OBJECT (held through a weak reference: a new module

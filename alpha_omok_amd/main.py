@@ -319,7 +319,8 @@ def train_batch(batch):
         p_loss = -(pi_batch * p_batch.log()).sum(dim=-1).mean()
         loss = v_loss + p_loss
         loss.backward()
-    _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0)
+    # each rank's gradient counts for the samples behind it (a shard that ran short contributes a partial batch)
+    _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0, weight=len(batch))
     if contributors == 0:
         return None
     optimizer.step()
@@ -410,6 +411,11 @@ def save_dataset(memory, n_iter, step_, directory='data', datetime_now=None):
     datetime_now = datetime_now or datetime.now().strftime('%y%m%d')
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, '{}_{}_{}_step_dataset.pickle'.format(datetime_now, n_iter, step_))
+    # replay memories are rank-local under torch.distributed: rank 0 writes the reference's file name, every other rank
+    # its own shard beside it (<name>.rank<r>of<w>), so a resume loses nobody's samples (load_data)
+    rank, world = parallel.world()
+    if world > 1 and rank > 0:
+        path += '.rank{}of{}'.format(rank, world)
     if not isinstance(memory, deque):                     # DeviceReplay: pickle what the reference pickles
         memory = deque(list(memory), maxlen=memory.maxlen)
     with open(path, 'wb') as f:
@@ -434,8 +440,24 @@ def load_data(model_path, dataset_path):
         step = int(name.split('_')[2])
         start_iter = int(name.split('_')[1]) + 1
     if dataset_path:
+        import glob
+        rank, world = parallel.world()
         with open(dataset_path, 'rb') as f:
             loaded = pickle.load(f)
+        shards = sorted(glob.glob(glob.escape(dataset_path) + '.rank*of*'))
+        own = dataset_path + '.rank{}of{}'.format(rank, world)
+        if world > 1 and len(shards) == world - 1 and (rank == 0 or own in shards):
+            # written by a job of this shape: every rank takes its own shard back
+            if rank > 0:
+                with open(own, 'rb') as f:
+                    loaded = pickle.load(f)
+        elif world > 1 or shards:
+            # another shape (or a single-process file): pool what there is and deal it out entry i -> rank i % world
+            pool = list(loaded)
+            for sp in shards:
+                with open(sp, 'rb') as f:
+                    pool.extend(pickle.load(f))
+            loaded = pool[rank::world]
         if hasattr(rep_memory, "extend_augmented"):
             rep_memory.clear()
             rep_memory.extend(loaded)
@@ -466,9 +488,10 @@ def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, sa
             train(N_EPOCHS, n_iter)
         else:
             self_play(n_first)
-        if n_iter % save_every == 0 and parallel.world()[0] == 0:
-            save_model(Agent, n_iter + save_every, step, directory)
-            save_dataset(rep_memory, n_iter + save_every, step, directory)
+        if n_iter % save_every == 0:
+            if parallel.world()[0] == 0:
+                save_model(Agent, n_iter + save_every, step, directory)
+            save_dataset(rep_memory, n_iter + save_every, step, directory)   # every rank: its own shard
         reset_iter(result, cur_memory)
         done += 1
     return done

@@ -90,31 +90,39 @@ def agree(value, op="max", device=None):
     return int(t.item())
 
 
-def allreduce_gradients(module, contributes=True):
-    """grad <- mean over the CONTRIBUTING ranks, through ONE flattened fp32 buffer (ncclAllReduce(sum)).
+def allreduce_gradients(module, contributes=True, weight=1.0):
+    """grad <- weighted mean over the CONTRIBUTING ranks, through ONE flattened fp32 buffer (ncclAllReduce(sum)).
 
     Every rank calls this once per mini-batch, whether or not it had a batch of its own: a rank without
     one (empty replay shard, fewer samples than the agreed step count) passes contributes=False and adds
-    zeros. The last element of the buffer counts the contributors, so the divisor travels in the same
-    message. Returns (elements reduced, contributing ranks); with one process it is a no-op."""
+    zeros. `weight` is the number of samples behind this rank's gradient (main.train_batch passes len(batch)): the
+    local gradient -- a mean over the local batch -- is scaled by it and the last element of the buffer carries the
+    weights' sum, so the result is the gradient of the mean loss over the UNION of the ranks' batches and a rank whose
+    shard ran short (a partial batch) counts for what it holds, not for a full share. The divisor travels in the same
+    message. Returns (elements reduced, summed weight: the number of contributing ranks when every weight is 1);
+    without a process group it is a no-op."""
     import torch.distributed as dist
     params = [p for p in module.parameters() if p.requires_grad]
+    weight = float(weight) if contributes else 0.0
     if not _collectives_on():
-        return sum(p.numel() for p in params), 1 if contributes else 0
+        return sum(p.numel() for p in params), (int(weight) if weight == int(weight) else weight)
     dev = params[0].device
     if contributes:
         parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
     else:
         parts = [torch.zeros(p.numel(), dtype=p.dtype, device=dev) for p in params]
-    parts.append(torch.full((1,), 1.0 if contributes else 0.0, dtype=parts[0].dtype, device=dev))
+    parts.append(torch.full((1,), 1.0, dtype=parts[0].dtype, device=dev))
     flat = torch.cat(parts)
+    if weight != 1.0:
+        flat.mul_(weight)                                 # (the trailing 1 becomes the weight)
     buf = _staged(flat)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     if buf is not flat:
         flat.copy_(buf)
-    count = int(round(float(flat[-1].item())))
-    if count > 0:
-        flat.div_(count)
+    total = float(flat[-1].item())
+    count = int(round(total)) if abs(total - round(total)) < 1e-3 else total
+    if total > 0:
+        flat.div_(total)
     off = 0
     for p in params:
         k = p.numel()

@@ -146,7 +146,15 @@ def _ddp_worker(rank, world, port, out):
     n, contributors = parallel.allreduce_gradients(net)
     assert contributors == world
     flat = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
-    torch.save(dict(same=same, n=n, grad=flat, shard=parallel.shard_games(10, rank, world)), out % rank)
+    # unequal shards (5 + 3 samples): each rank's mean gradient counts for the samples behind it
+    net.zero_grad()
+    su = slice(0, 5) if rank == 0 else slice(5, 8)
+    p, v = net(x[su])
+    ((v - z[su]).pow(2).mean() - (pi[su] * p.log()).sum(-1).mean()).backward()
+    n2, wsum = parallel.allreduce_gradients(net, weight=su.stop - su.start)
+    assert wsum == 8 and n2 == n
+    flat_w = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
+    torch.save(dict(same=same, n=n, grad=flat, grad_w=flat_w, shard=parallel.shard_games(10, rank, world)), out % rank)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -176,6 +184,9 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     full = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
     assert r0["n"] == full.numel()
     assert (r0["grad"] - full).abs().max().item() < 1e-5
+    # 5 + 3 samples, weighted by their counts: still the gradient of the mean loss over all 8
+    assert torch.equal(r0["grad_w"], r1["grad_w"])
+    assert (r0["grad_w"] - full).abs().max().item() < 1e-5
 
 
 def _train_worker(rank, world, port, out, n_cur, n_rep):
@@ -226,6 +237,47 @@ def test_gloo_world2_train_with_unequal_memories(tmp_path, n_cur, n_rep, steps, 
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     assert int(r0["sd"]["bn1.num_batches_tracked"]) == max(n_losses)
+
+
+def _shard_worker(rank, world, port, directory, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from alpha_omok_amd import main, parallel
+    parallel.init_from_env("gloo")
+    main.rep_memory = __import__("collections").deque(maxlen=main.MEMORY_SIZE)
+    mine = [(np.full((5, 9, 9), float(rank)), np.ones(81) / 81, float(100 * rank + i)) for i in range(4 + rank)]
+    main.rep_memory.extend(mine)
+    path = main.save_dataset(main.rep_memory, 300, 77, directory=directory, datetime_now="180927")
+    dist.barrier()
+    main.rep_memory.clear()
+    main.load_data(None, os.path.join(directory, "180927_300_77_step_dataset.pickle"))
+    back = [m[2] for m in main.rep_memory]
+    torch.save(dict(path=path, mine=[m[2] for m in mine], back=back), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_dataset_shards_survive_save_and_resume(tmp_path):
+    """Replay memories are rank-local: every rank writes its shard (rank 0 under the reference's file name), a resume
+    of the same shape gives every rank its own samples back, and a single-process resume pools all of them."""
+    import torch
+    import torch.multiprocessing as mp
+    from collections import deque
+    from alpha_omok_amd import main
+    port = 29500 + random.randint(0, 2000)
+    out = str(tmp_path / "s%d.pt")
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert os.path.basename(r0["path"]) == "180927_300_77_step_dataset.pickle"
+    assert os.path.basename(r1["path"]) == "180927_300_77_step_dataset.pickle.rank1of2"
+    assert r0["back"] == r0["mine"] and r1["back"] == r1["mine"] and len(r1["mine"]) == 5
+    main.rep_memory = deque(maxlen=main.MEMORY_SIZE)
+    main.load_data(None, r0["path"])                   # one process: everything, nobody's samples lost
+    assert sorted(m[2] for m in main.rep_memory) == sorted(r0["mine"] + r1["mine"])
+    main.rep_memory.clear()
 
 
 def test_train_raises_like_the_reference_when_replay_is_too_small():
