@@ -356,39 +356,78 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
     float* s_h = s_w3 + 3 * planes;     // [16 boards][3][A]
     for (int i = tid; i < 3 * planes; i += nthreads) s_w3[i] = a.w3[i];
     __syncthreads();
-    {
+    if (H16 != 0) {
+        // split-fp16 layouts: a lane's 8 channels of one (cell, 32-channel block, oct) are ONE 16-byte slot of the high
+        // fragment (+ 16 / 8 bytes of the low one). All slots of two blocks are requested before the first is used: written
+        // quad by quad this loop was a chain of 32 dependent round trips per cell to data that has mostly left L2 by
+        // now (0.10 M of the launch's 2.75 M cycles, profiles/r3a_trunk16h_bytes_ko.txt).
+        const int b = tid & 15;
+        const int nblk = CQ >> 3;
+        for (int cell = tid >> 4; cell < A; cell += nthreads >> 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            constexpr int CB = 4;   // blocks in flight (the split-fp16 kernels are built for 128 planes = 4 blocks)
+            for (int c0 = 0; c0 < nblk; c0 += CB) {
+                uint4 hv[CB][4], lv[CB][4];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) {
+                        const int c = c0 + cb < nblk ? c0 + cb : nblk - 1;
+                        const char* base = reinterpret_cast<const char*>(act) +
+                                           ((gbase + cell) * nblk + c) * (H16 == 2 ? 1536 : 2048) + (oc * 16 + b) * 16;
+                        hv[cb][oc] = *reinterpret_cast<const uint4*>(base);
+                        if (H16 == 2) {
+                            const uint2 t = *reinterpret_cast<const uint2*>(base + 1024 - (oc * 16 + b) * 8);
+                            lv[cb][oc] = make_uint4(t.x, t.y, 0u, 0u);
+                        } else {
+                            lv[cb][oc] = *reinterpret_cast<const uint4*>(base + 1024);
+                        }
+                    }
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    if (c0 + cb >= nblk) continue;
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) {
+                        const unsigned hw[4] = {hv[cb][oc].x, hv[cb][oc].y, hv[cb][oc].z, hv[cb][oc].w};
+                        const unsigned lw[4] = {lv[cb][oc].x, lv[cb][oc].y, lv[cb][oc].z, lv[cb][oc].w};
+                        float x[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned hb = (hw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                            if (H16 == 2) {
+                                const unsigned t = (hb << 8) | ((lw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                                x[k] = __uint_as_float(t ? (t << 5) + 0x38000000u : 0u);
+                            } else {
+                                const unsigned lb = (lw[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                                x[k] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(hb))) +
+                                       static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(lb)));
+                            }
+                        }
+                        const int ch = ((c0 + cb) * 4 + oc) * 8;   // first channel of this slot
+                        const float* w0 = s_w3 + ch;
+                        const float* w1 = s_w3 + planes + ch;
+                        const float* w2 = s_w3 + 2 * planes + ch;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            a0 = fmaf(x[k], w0[k], a0);
+                            a1 = fmaf(x[k], w1[k], a1);
+                            a2 = fmaf(x[k], w2[k], a2);
+                        }
+                    }
+                }
+            }
+            float* h = s_h + b * 3 * A + cell;
+            h[0] = fmaxf(fmaf(a0, a.sc3[0], a.sh3[0]), 0.f);
+            h[A] = fmaxf(fmaf(a1, a.sc3[1], a.sh3[1]), 0.f);
+            h[2 * A] = fmaxf(fmaf(a2, a.sc3[2], a.sh3[2]), 0.f);
+        }
+    } else {
         const int b = tid & 15;
         for (int cell = tid >> 4; cell < A; cell += nthreads >> 4) {
             const float4* xp = act + ((gbase + cell) * CQ) * GB + b;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             for (int cq = 0; cq < CQ; ++cq) {
-                float4 x;
-                if (H16 == 2) {
-                    // [cell][c32]{[oct 4][board 16][8 halfs] | [oct 4][board 16][8 bytes]}: 1536 B per (cell, block)
-                    const char* base = reinterpret_cast<const char*>(act) + ((gbase + cell) * (CQ >> 3) + (cq >> 3)) * 1536;
-                    const int slot = ((cq & 7) >> 1) * 16 + b;
-                    const uint2 hw = *reinterpret_cast<const uint2*>(base + slot * 16 + (cq & 1) * 8);
-                    const unsigned lw = *reinterpret_cast<const unsigned*>(base + 1024 + slot * 8 + (cq & 1) * 4);
-                    auto val = [](unsigned h, unsigned l) {
-                        const unsigned t = (h << 8) | l;
-                        return __uint_as_float(t ? (t << 5) + 0x38000000u : 0u);
-                    };
-                    x = make_float4(val(hw.x & 0xffffu, lw & 0xffu), val(hw.x >> 16, (lw >> 8) & 0xffu),
-                                    val(hw.y & 0xffffu, (lw >> 16) & 0xffu), val(hw.y >> 16, lw >> 24));
-                } else if (H16) {
-                    // [cell][c32][split][kq 4][board 16][8 halfs]: quad cq = halfs (cq&1)*4.. of oct (cq&7)>>1 of block cq>>3
-                    const char* base = reinterpret_cast<const char*>(act) +
-                                       ((((gbase + cell) * (CQ >> 3) + (cq >> 3)) * 2) * 64 + ((cq & 7) >> 1) * 16 + b) * 16 +
-                                       (cq & 1) * 8;
-                    const half4 hh = *reinterpret_cast<const half4*>(base);
-                    const half4 hl = *reinterpret_cast<const half4*>(base + 1024);
-                    x = make_float4(static_cast<float>(hh[0]) + static_cast<float>(hl[0]),
-                                    static_cast<float>(hh[1]) + static_cast<float>(hl[1]),
-                                    static_cast<float>(hh[2]) + static_cast<float>(hl[2]),
-                                    static_cast<float>(hh[3]) + static_cast<float>(hl[3]));
-                } else {
-                    x = xp[static_cast<size_t>(cq) * GB];
-                }
+                const float4 x = xp[static_cast<size_t>(cq) * GB];
                 const float* w0 = s_w3 + 4 * cq;
                 const float* w1 = s_w3 + planes + 4 * cq;
                 const float* w2 = s_w3 + 2 * planes + 4 * cq;
@@ -420,6 +459,7 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
 #pragma unroll
                 for (int bb = 0; bb < GB; ++bb) acc[bb] = 0.f;
                 if (o < A) {
+#pragma unroll 4
                     for (int j = j0; j < j1; ++j) {
                         const float w = a.wp_t[static_cast<size_t>(j) * A + o];
 #pragma unroll
@@ -438,6 +478,7 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
 #pragma unroll
                 for (int bb = 0; bb < GB; ++bb) acc[bb] = 0.f;
                 if (o < planes) {
+#pragma unroll 4
                     for (int j = j0; j < j1; ++j) {
                         const float w = a.w1_t[static_cast<size_t>(j) * planes + o];
 #pragma unroll

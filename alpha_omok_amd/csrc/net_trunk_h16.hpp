@@ -95,6 +95,9 @@ __device__ unsigned long long ao_prof[8 * 12];
 #ifndef AO_SPLIT_BARRIER
 #define AO_SPLIT_BARRIER 0
 #endif
+#ifndef AO_CONV1_SPLIT
+#define AO_CONV1_SPLIT 0   // 1: conv1 on bit planes requests the next row's bytes one slab before they are written to LDS -- measured neutral (r3j: 1.3964 / 1.3953 ms), off
+#endif
 __device__ __forceinline__ void row_arrive(unsigned* cnt, int lane) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -215,6 +218,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         return h;
     };
     float peak = 0.f;  // largest pre-clamp activation this lane wrote
+    unsigned pbits[BITS ? (NFR + NT - 1) / NT : 1] = {};   // conv1 on bit planes: plane bytes of the next row in flight
     f32x4 acc[3][BW];  // output rows yi-1, yi, yi+1
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -398,6 +402,26 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                 constexpr int K2 = (NPAIR / NT + NCI - 1) / (NCI > 1 ? NCI - 1 : 1);   // shares in blocks 0 .. NCI-2, the last block only expands
                 if (c > 0 && AO_KO != 11) expand_pairs(xn, (c - 1) * K2, c * K2);   // (AO_KO 11: no expansion, timing only)
                 if (c + 1 < NCI) stage_pairs(yn, xn, c * K2, (c + 1) * K2);
+            } else if (BITS && AO_KO != 3 && AO_CONV1_SPLIT) {
+                // conv1 on bit planes: the next row's plane bytes are requested in the first slab of the row and turned
+                // into fragments in the last one, so the byte loads' round trip is covered by a slab of MFMAs (a conv1
+                // row has only three slabs; load and LDS write in the same slab stalled every row)
+                constexpr int KF = (NFR + NT - 1) / NT;
+#pragma unroll
+                for (int k = 0; k < KF; ++k) {
+                    const int f = tile + NT * k;
+                    if (f < NFR) {
+                        if (dy == 0 && !(f & 1))
+                            pbits[k] = __builtin_amdgcn_raw_buffer_load_b8(rs_src, b * kPlaneRow(BW) + yn * BW + (f >> 1), 0, 0);
+                        if (dy == 2) {
+                            half8 h;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                h[q] = (kq == 0 && !(f & 1) && ((pbits[k] >> q) & 1u)) ? static_cast<_Float16>(1.0f) : static_cast<_Float16>(0.0f);
+                            xn[f * 64 + lane] = __builtin_bit_cast(uint4, h);
+                        }
+                    }
+                }
             } else if (dy == 1 && AO_KO != 3) {
                 // next input row into LDS, a share per block (always-executed slab)
 #pragma unroll
