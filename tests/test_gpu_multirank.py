@@ -168,3 +168,28 @@ def test_one_rank_rccl_group_runs_every_collective_on_device_buffers(tmp_path):
     mp.spawn(_rccl_worker, args=(1, port, out), nprocs=1, join=True)
     r = torch.load(out, weights_only=False)
     assert r["backend"] == "nccl" and r["rccl_mapped"], "librccl is not mapped: the nccl backend did not load RCCL"
+
+
+def test_bench_self_launches_two_ranks_with_training_step(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (torch.distributed.run on
+    127.0.0.1) and reports n_gpus = 2 with the configs[3] training step inside the timed region. On this 1-GPU box the
+    ranks share cuda:0 and the collective runs over gloo (AO_BENCH_SHARE_GPU / AO_BENCH_BACKEND: RCCL refuses two
+    ranks on one device); on an N-GPU node the same command runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AO_BENCH_SHARE_GPU="1", AO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "64",
+           "--sims", "16", "--blocks", "1", "--prefill-games", "3", "--prefill-sims", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 64 * 2 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)   # both ranks' move decisions / max time
+    ts = d["train_step"]
+    assert ts["allreduce_ranks"] == 2 and ts["allreduce_backend"] == "gloo" and ts["train_steps"] == 2 and ts["inside_timed_region"]
+    assert ts["allreduce_elements"] > 1000 and ts["mean_loss"] is not None and np.isfinite(ts["mean_loss"])
