@@ -12,7 +12,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1x"
 out = os.path.join(REPO, "gpurun_out", "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block",
+cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block", "--no-tictactoe",
        "--steps", "1", "--warmup", "0", "--sims", "20"]
 GROUPS = {
     "waves": ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"],
