@@ -416,10 +416,11 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
                     }
                 }
             }
-            float* h = s_h + b * 3 * A + cell;
-            h[0] = fmaxf(fmaf(a0, a.sc3[0], a.sh3[0]), 0.f);
-            h[A] = fmaxf(fmaf(a1, a.sc3[1], a.sh3[1]), 0.f);
-            h[2 * A] = fmaxf(fmaf(a2, a.sc3[2], a.sh3[2]), 0.f);
+            // s_h is [3A][16 boards] here: the FC sweeps below read the 16 boards of an input index as four 16-byte
+            // broadcasts instead of sixteen 4-byte ones (the sweeps were LDS-instruction bound: ~60 k of the heads' 88 k cycles)
+            s_h[(cell) * GB + b] = fmaxf(fmaf(a0, a.sc3[0], a.sh3[0]), 0.f);
+            s_h[(A + cell) * GB + b] = fmaxf(fmaf(a1, a.sc3[1], a.sh3[1]), 0.f);
+            s_h[(2 * A + cell) * GB + b] = fmaxf(fmaf(a2, a.sc3[2], a.sh3[2]), 0.f);
         }
     } else {
         const int b = tid & 15;
@@ -462,8 +463,13 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
 #pragma unroll 4
                     for (int j = j0; j < j1; ++j) {
                         const float w = a.wp_t[static_cast<size_t>(j) * A + o];
+                        const float4* hq = reinterpret_cast<const float4*>(s_h + j * GB);
 #pragma unroll
-                        for (int bb = 0; bb < GB; ++bb) acc[bb] = fmaf(w, s_h[bb * 3 * A + j], acc[bb]);
+                        for (int q = 0; q < GB / 4; ++q) {
+                            const float4 h4 = hq[q];
+                            acc[4 * q] = fmaf(w, h4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w, h4.y, acc[4 * q + 1]);
+                            acc[4 * q + 2] = fmaf(w, h4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w, h4.w, acc[4 * q + 3]);
+                        }
                     }
 #pragma unroll
                     for (int bb = 0; bb < GB; ++bb) s_pp[(wave * GB + bb) * A + o] = acc[bb];
@@ -481,8 +487,13 @@ __device__ __forceinline__ void trunk_heads(const Args& a, const float4* act, si
 #pragma unroll 4
                     for (int j = j0; j < j1; ++j) {
                         const float w = a.w1_t[static_cast<size_t>(j) * planes + o];
+                        const float4* hq = reinterpret_cast<const float4*>(s_h + (2 * A + j) * GB);
 #pragma unroll
-                        for (int bb = 0; bb < GB; ++bb) acc[bb] = fmaf(w, s_h[bb * 3 * A + 2 * A + j], acc[bb]);
+                        for (int q = 0; q < GB / 4; ++q) {
+                            const float4 h4 = hq[q];
+                            acc[4 * q] = fmaf(w, h4.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w, h4.y, acc[4 * q + 1]);
+                            acc[4 * q + 2] = fmaf(w, h4.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w, h4.w, acc[4 * q + 3]);
+                        }
                     }
 #pragma unroll
                     for (int bb = 0; bb < GB; ++bb) s_vp[(wave * GB + bb) * planes + o] = acc[bb];
