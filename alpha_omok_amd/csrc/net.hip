@@ -150,6 +150,11 @@ static void timer_end(ao_net* n, int idx, hipStream_t s) {
 
 // mode 5 (split-fp16 MFMA trunk: k_trunk16h resident for boards up to 9x9 with >= 192 groups, k_layer16h per
 // layer otherwise) is built for 128 planes and at least one ResBlock
+// mode 6: the per-layer split-fp16 kernels for EVERY batch size (never the resident trunk, never the per-board path), so
+// that what evaluates a position -- and therefore a game's whole trajectory -- does not depend on how many other games
+// share the batch. k_layer16h's arithmetic per output element is the same for any chunking and any neighbour boards.
+static bool layers_only(const ao_net* n) { return n->mode == 6; }
+
 static bool h16_supported(const ao_net* n) {
     return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
@@ -176,6 +181,7 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     // measured cross-overs (us per simulation, 9x9, 4 blocks): per-board path vs fp32 row-chunked layers 529 / 676
     // at 128 boards and 979 / 676 at 256; per-board path vs split-fp16 layers 174 / 246 at 32 boards and 307 / 258
     // at 64 (15x15, 10 blocks: 518 / 501 at 16 boards)
+    if (mode == 6) mode = 5;   // mode 6 = mode 5 restricted to the per-layer kernels (layers_only()): one arithmetic for every batch size
     if (mode == 0) {
         const long cells = static_cast<long>(boards) * n->A;
         if (h16_supported(n)) mode = cells <= 3800 ? 3 : 5;
@@ -344,9 +350,9 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         NET_HIP(n, hipGetLastError());
         return 0;
 #ifdef AO_PROF
-    } else if (group == 16 && mode == 5 && !(n->B <= 9 && (groups >= 192 || getenv("AO_FORCE_RESIDENT")))) {
+    } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (groups >= 192 || getenv("AO_FORCE_RESIDENT"))))) {
 #else
-    } else if (group == 16 && mode == 5 && !(n->B <= 9 && groups >= 192)) {
+    } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && groups >= 192))) {
 #endif
         // split-fp16 trunk, one launch per conv: workgroup = (16-board group, row chunk, column tile). For batches
         // that cannot give every CU a whole group, and for boards wider than 9 (a staged row must fit LDS twice)
@@ -625,10 +631,11 @@ void ao_net_destroy(ao_net* n) {
 }
 
 int ao_net_set_mode(ao_net* n, int mode) {
-    if (mode < 0 || mode > 5)
-        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board), 4 (row-chunked) or 5 (split-fp16 trunk)");
-    if (mode == 5 && !h16_supported(n))
-        return n->fail("mode 5 (split-fp16 MFMA trunk) needs 128 planes and at least one ResBlock");
+    if (mode < 0 || mode > 6)
+        return n->fail("mode must be 0 (auto), 1 (layer kernels), 2 (group-resident trunk), 3 (per-board), 4 (row-chunked), 5 (split-fp16 trunk) "
+                       "or 6 (split-fp16 per-layer kernels for every batch size)");
+    if ((mode == 5 || mode == 6) && !h16_supported(n))
+        return n->fail("modes 5 / 6 (split-fp16 MFMA trunk) need 128 planes and at least one ResBlock");
     n->mode = mode;
     return 0;
 }
@@ -900,7 +907,7 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
     } else if (group == 16 && mode == 4) {
         nm = "k_layer16<" + bw + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
-    } else if (group == 16 && mode == 5 && !(n->B <= 9 && (boards + 15) / 16 >= 192)) {
+    } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (boards + 15) / 16 >= 192))) {
         nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
              "16-board groups x row chunks x column tiles)";
         f = conv;
@@ -940,7 +947,7 @@ int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, doub
 int ao_net_plan_kernel(int n_block, int inplanes, int planes, int board, int trunk_mode, int boards, int in_kind,
                        char* name, int name_cap, double* flop_per_launch) {
     if (n_block < 0 || inplanes < 1 || planes < 32 || planes % 32 || board < 3 || board > ao::kMaxBoard || boards < 1 ||
-        trunk_mode < 0 || trunk_mode > 5)
+        trunk_mode < 0 || trunk_mode > 6)
         return 1;
     ao_net n;   // never finalized, owns nothing: the planning fields of ao_net_create without a device
     n.nb = n_block; n.C = inplanes; n.planes = planes; n.B = board; n.A = board * board;

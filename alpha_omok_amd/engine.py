@@ -93,7 +93,8 @@ class Net:
 
     def set_mode(self, mode):
         """0 auto, 1 layer kernels (32-board groups), 2 group-resident trunk, 3 per-board, 4 row-chunked layers,
-        5 group-resident trunk on split-fp16 MFMAs (fp32-accurate; 128 planes, board <= 9x9)."""
+        5 group-resident trunk on split-fp16 MFMAs (fp32-accurate; 128 planes, board <= 9x9), 6 the per-layer split-fp16
+        kernels for every batch size (a position's evaluation then does not depend on what else is in the batch)."""
         self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
 
     def status(self, clear=True, stream=None):

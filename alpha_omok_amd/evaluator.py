@@ -21,6 +21,7 @@ class Evaluator:
         self._net = None
         self._bufs = None
         self._warned_width = False
+        self.net_mode = 0      # ao_net_set_mode of the exported network (6: one kernel family for every batch size)
 
     def native_net(self, model, board_size, inplanes):
         cfg = pvnet.looks_like_pvnet(model)
@@ -48,6 +49,8 @@ class Evaluator:
                 self._net = Net(cfg[0], cfg[1], cfg[2], cfg[3], self.device)
                 self._cfg = cfg
             self._net.load_state_dict(model.state_dict())
+            if self.net_mode:
+                self._net.set_mode(self.net_mode)
             self._key = (cfg, version)
             try:
                 self._ref = weakref.ref(model)

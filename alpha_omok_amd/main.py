@@ -77,11 +77,13 @@ trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since 
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
-              model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None):
+              model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
     node_cap: expanded-node capacity of a game's tree arena (0 = 4*(n_mcts+1), -1 = grow into the free HBM);
     strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
-    logged and `trim_stats` / self_play's return value carry the counters)."""
+    logged and `trim_stats` / self_play's return value carry the counters). reproducible=True evaluates every batch
+    size with ONE kernel family (ao_net_set_mode 6): an episode's samples then depend on its seed only, not on how many
+    other episodes share the engine or on MAX_CONCURRENT (slower for very small and very large batches)."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
     global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP
     STRICT = STRICT if strict is None else bool(strict)
@@ -111,6 +113,7 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
         optimizer = torch.optim.Adam(Agent.model.parameters(), lr=LR, weight_decay=L2, eps=1e-6)
     _engine = None
     _evaluator = Evaluator(gpu)
+    _evaluator.net_mode = 6 if reproducible else 0
     _episodes_played = 0
     if device_replay:
         from .replay import DeviceReplay

@@ -143,6 +143,45 @@ def test_self_play_concurrent_episodes_match_oracle_games(oracle):
     assert len(main.rep_memory) == min(8 * len(cm), main.MEMORY_SIZE)
 
 
+def test_reproducible_mode_makes_an_episode_independent_of_its_neighbours():
+    """configure(reproducible=True) = ao_net_set_mode 6: the per-layer split-fp16 kernels evaluate every batch size, so an
+    episode's samples depend on its seed only. The same three seeds are played alone (one slot each), two at a time and
+    among 150 other episodes with a real (default-initialised) network: identical samples, bit for bit. (In the default
+    mode the kernel family follows the number of active games -- per-board path, per-layer kernels, resident trunk --
+    and their fp32 roundings differ by ~1e-7, which a long game eventually turns into another move.)"""
+    import torch
+    import alpha_omok_amd.main as main
+    B, S = 9, 24
+    seeds3 = [901, 902, 903]
+
+    def play(n, seeds, conc):
+        torch.manual_seed(3)
+        main.MAX_CONCURRENT = conc
+        main.configure(board_size=B, n_mcts=S, n_blocks=2, in_planes=5, out_planes=128, seed=0, reproducible=True, node_cap=0, strict=True)
+        main.cur_memory.clear()
+        main.rep_memory.clear()
+        main.self_play(n, seeds=seeds)
+        main.MAX_CONCURRENT = 4096
+        mem = list(main.cur_memory)
+        eps = []
+        for s, p, z in mem:
+            if not s[:4].any():
+                eps.append([])
+            eps[-1].append((s.copy(), p.copy(), z))
+        return eps
+
+    alone = [play(1, [sd], 1)[0] for sd in seeds3]
+    pair = play(3, seeds3, 2)
+    crowd = play(153, seeds3 + list(range(5000, 5150)), 4096)[:3]
+    for e in range(3):
+        for other in (pair[e], crowd[e]):
+            assert len(other) == len(alone[e]), "episode %d: %d plies alone, %d with neighbours" % (e, len(alone[e]), len(other))
+            for (s0, p0, z0), (s1, p1, z1) in zip(alone[e], other):
+                assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+    main.configure(board_size=B, n_mcts=S, n_blocks=2, out_planes=128, seed=0, reproducible=False, strict=False)
+    main.release_engine()
+
+
 def test_self_play_reports_arena_trims_and_strict_mode_raises(oracle):
     """A tree arena too small for what the searches keep from move to move makes re-rooting forget subtrees -- a
     divergence from the reference's never-pruned dict (agents.py:52) that must not pass silently: self_play returns /
