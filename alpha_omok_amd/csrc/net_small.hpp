@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
     float lmax = -3.0e38f;
     for (int a = threadIdx.x; a < A; a += blockDim.x) {
         float acc = bp[a];
+        // (unrolled: 16 coalesced weight loads in flight per thread instead of one -- 70 -> 32 us for 1024 15x15 boards, r3r)
+#pragma unroll 16
         for (int j = 0; j < 2 * A; ++j) acc = fmaf(wp_t[static_cast<size_t>(j) * A + a], s_h[j], acc);
         s_logit[a] = acc;
         lmax = fmaxf(lmax, acc);
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
     // value head
     for (int o = threadIdx.x; o < planes; o += blockDim.x) {
         float acc = b1[o];
+#pragma unroll 16
         for (int j = 0; j < A; ++j) acc = fmaf(w1_t[static_cast<size_t>(j) * planes + o], s_h[2 * A + j], acc);
         s_hid[o] = fmaxf(acc, 0.f);
     }
