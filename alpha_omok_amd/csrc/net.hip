@@ -345,9 +345,18 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
         }
         const size_t lds1 = heads_lds_floats(n->A, n->planes) * sizeof(float);
-        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(512), lds1, s, head_params(n),
+        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(1024), lds1, s, head_params(n),
                            reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
+#ifdef AO_PROF
+        if (getenv("AO_PROF_PRINT")) {
+            unsigned long long h[8];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof_heads), sizeof(h));
+            fprintf(stderr, "AO_PROF k_heads_board ticks: w3 %llu, 1x1 conv %llu, reduce %llu, FC %llu, softmax+value %llu, tanh/store %llu, total %llu\n",
+                    h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+        }
+#endif
         return 0;
 #ifdef AO_PROF
     } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (groups >= 192 || getenv("AO_FORCE_RESIDENT"))))) {

@@ -137,7 +137,7 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
 
 // LDS floats heads_board_dev needs
 __host__ __device__ inline size_t heads_lds_floats(int A, int planes) {
-    return static_cast<size_t>(3) * planes + 3 * A + 6 * A + 4 * A + 2 * planes + planes + 16;
+    return static_cast<size_t>(3) * planes + 3 * A + 36 * A + 6 * A + 4 * planes + planes + 16;
 }
 
 // Policy and value heads of ONE board (model.py:34-73) by one workgroup of any size >= 64:
@@ -146,12 +146,20 @@ __host__ __device__ inline size_t heads_lds_floats(int A, int planes) {
 // slices so that all threads carry a short, independent chain of loads (the weight matrices come
 // from L2: 52 KB + 41 KB at 9x9), partial sums meet in LDS.
 // act = this board's activations [A][planes/4]; policy -> [A], value -> [1]. All threads must call.
+#ifdef AO_PROF
+__device__ unsigned long long ao_prof_heads[8];   // phase ends of k_heads_board (thread 0 of board 0), shader-clock ticks
+#define AO_HT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_heads[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AO_HT(k)
+#endif
 __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float4* __restrict__ act,
                                                 float* __restrict__ policy, float* __restrict__ value, int A,
                                                 int planes, float* s_mem) {
-    constexpr int KS = 2;   // K slices of the 1x1 convs
-    constexpr int NPS = 4;  // slices of the 2A-long policy_fc dot products
-    constexpr int NVS = 2;  // slices of the A-long value_fc1 dot products
+    constexpr int KS = 12;  // K slices of the 1x1 convs: a work item = (slice, cell) and forms all three head channels from
+                            // its activation quads (9x9: 972 items for 1024 threads, 3 quads each -- one round)
+    constexpr int NPS = 6;  // slices of the 2A-long policy_fc dot products (9x9: 486 + 512 FC items <= 1024 threads: one round of
+                            // 27 / 21 weights per thread; a second round of a few items keeps the whole block waiting)
+    constexpr int NVS = 4;  // slices of the A-long value_fc1 dot products
     float* s_w3 = s_mem;                 // [3*planes]
     float* s_h = s_w3 + 3 * planes;      // [3A]
     float* s_hp = s_h + 3 * A;           // [KS][3A]
@@ -161,33 +169,45 @@ __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float
     float* s_red = s_hid + planes;       // [16]
     const int tid = threadIdx.x, nt = blockDim.x;
     const int CQ = planes >> 2;
+    AO_HT(0);
     for (int i = tid; i < 3 * planes; i += nt) s_w3[i] = h.w3[i];
     __syncthreads();
-    // 1x1 convs: (K slice, output channel, cell) per thread
+    AO_HT(1);
+    // the per-output constants of the later phases are requested now: each was a dependent L2 round trip in its phase
+    const float bp_r = tid < A ? h.bp[tid] : 0.f;
+    const float b2_r = h.b2[0];
+    // 1x1 convs: (K slice, cell) per thread, the three output channels together: a quad is loaded once and its twelve
+    // weights come as three 16-byte LDS reads (was: one item per channel, 64 four-byte LDS reads per item)
     const int cqs = (CQ + KS - 1) / KS;
-    for (int i = tid; i < KS * 3 * A; i += nt) {
-        const int ks = i / (3 * A), r = i - ks * 3 * A;
-        const int c = r / A, cell = r - c * A;
+    for (int i = tid; i < KS * A; i += nt) {
+        const int ks = i / A, cell = i - ks * A;
         const int q0 = ks * cqs, q1 = min(CQ, q0 + cqs);
         const float4* xp = act + static_cast<size_t>(cell) * CQ;
-        const float* w = s_w3 + c * planes;
-        float a0 = 0.f, a1 = 0.f;
-        int cq = q0;
-        for (; cq + 1 < q1; cq += 2) {
-            const float4 x = xp[cq], y = xp[cq + 1];
-            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
-            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
-            a1 = fmaf(y.x, w[4 * cq + 4], a1); a1 = fmaf(y.y, w[4 * cq + 5], a1);
-            a1 = fmaf(y.z, w[4 * cq + 6], a1); a1 = fmaf(y.w, w[4 * cq + 7], a1);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        constexpr int XB = 3;
+        for (int qb = q0; qb < q1; qb += XB) {
+            float4 xr[XB];
+#pragma unroll
+            for (int k = 0; k < XB; ++k) xr[k] = (qb + k < q1) ? xp[qb + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < XB; ++k) {
+                if (qb + k < q1) {
+                    const float4 x = xr[k];
+                    const float4 w0 = *reinterpret_cast<const float4*>(s_w3 + 4 * (qb + k));
+                    const float4 w1 = *reinterpret_cast<const float4*>(s_w3 + planes + 4 * (qb + k));
+                    const float4 w2 = *reinterpret_cast<const float4*>(s_w3 + 2 * planes + 4 * (qb + k));
+                    a0 = fmaf(x.x, w0.x, a0); a0 = fmaf(x.y, w0.y, a0); a0 = fmaf(x.z, w0.z, a0); a0 = fmaf(x.w, w0.w, a0);
+                    a1 = fmaf(x.x, w1.x, a1); a1 = fmaf(x.y, w1.y, a1); a1 = fmaf(x.z, w1.z, a1); a1 = fmaf(x.w, w1.w, a1);
+                    a2 = fmaf(x.x, w2.x, a2); a2 = fmaf(x.y, w2.y, a2); a2 = fmaf(x.z, w2.z, a2); a2 = fmaf(x.w, w2.w, a2);
+                }
+            }
         }
-        if (cq < q1) {
-            const float4 x = xp[cq];
-            a0 = fmaf(x.x, w[4 * cq], a0); a0 = fmaf(x.y, w[4 * cq + 1], a0);
-            a0 = fmaf(x.z, w[4 * cq + 2], a0); a0 = fmaf(x.w, w[4 * cq + 3], a0);
-        }
-        s_hp[i] = a0 + a1;
+        s_hp[ks * 3 * A + cell] = a0;
+        s_hp[ks * 3 * A + A + cell] = a1;
+        s_hp[ks * 3 * A + 2 * A + cell] = a2;
     }
     __syncthreads();
+    AO_HT(2);
     for (int r = tid; r < 3 * A; r += nt) {
         const int c = r / A;
         float t = s_hp[r];
@@ -196,6 +216,7 @@ __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float
         s_h[r] = fmaxf(fmaf(t, h.sc3[c], h.sh3[c]), 0.f);
     }
     __syncthreads();
+    AO_HT(3);
     // policy_fc (NPS slices per output) and value_fc1 (NVS slices per hidden unit) in one sweep
     const int np_items = NPS * A, nv_items = NVS * planes;
     const int pslice = (2 * A + NPS - 1) / NPS, vslice = (A + NVS - 1) / NVS;
@@ -219,33 +240,57 @@ __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float
         }
     }
     __syncthreads();
-    float lmax = -3.0e38f;
-    for (int a = tid; a < A; a += nt) {
-        float l = h.bp[a];
+    AO_HT(4);
+    // softmax and the value head's tail by ONE wave each, on wave shuffles only: as block-wide reductions these were three
+    // rounds of two barriers with six idle waves (6 k of the kernel's 25 k cycles)
+    const int wave = tid >> 6, lane = tid & 63;
+    if (wave == 0) {
+        constexpr int NL = 4;                     // logits per lane: A <= 256
+        float lg[NL];
+        float lmax = -3.0e38f;
 #pragma unroll
-        for (int q = 0; q < NPS; ++q) l += s_part[q * A + a];
-        s_part[a] = l;
-        lmax = fmaxf(lmax, l);
-    }
-    for (int o = tid; o < planes; o += nt) {
-        float t = h.b1[o];
+        for (int k = 0; k < NL; ++k) {
+            const int a = lane + 64 * k;
+            lg[k] = -3.0e38f;
+            if (a < A) {
+                float l = (k == 0) ? bp_r : h.bp[a];
 #pragma unroll
-        for (int q = 0; q < NVS; ++q) t += s_vpart[q * planes + o];
-        s_hid[o] = fmaxf(t, 0.f);
+                for (int q = 0; q < NPS; ++q) l += s_part[q * A + a];
+                lg[k] = l;
+                lmax = fmaxf(lmax, l);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        float lsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int a = lane + 64 * k;
+            lg[k] = a < A ? expf(lg[k] - lmax) : 0.f;
+            lsum += lg[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int a = lane + 64 * k;
+            if (a < A) policy[a] = lg[k] / lsum;
+        }
     }
-    lmax = block_reduce(lmax, s_red, true);   // (its barriers also publish s_part / s_hid)
-    float lsum = 0.f;
-    for (int a = tid; a < A; a += nt) {
-        const float ex = expf(s_part[a] - lmax);
-        s_part[a] = ex;
-        lsum += ex;
+    if (wave == (nt > 64 ? 1 : 0)) {
+        float part = 0.f;
+        for (int o = lane; o < planes; o += 64) {
+            float t = h.b1[o];
+#pragma unroll
+            for (int q = 0; q < NVS; ++q) t += s_vpart[q * planes + o];
+            part = fmaf(h.w2[o], fmaxf(t, 0.f), part);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) value[0] = tanhf(part + b2_r);
     }
-    lsum = block_reduce(lsum, s_red, false);
-    for (int a = tid; a < A; a += nt) policy[a] = s_part[a] / lsum;
-    float part = 0.f;
-    for (int o = tid; o < planes; o += nt) part = fmaf(h.w2[o], s_hid[o], part);
-    part = block_reduce(part, s_red, false);
-    if (tid == 0) value[0] = tanhf(part + h.b2[0]);
+    AO_HT(5);
+    AO_HT(6);
 }
 
 }  // namespace ao

@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256) void k_head_fc(const float* __restrict__ hbuf,
 
 // Both heads of ONE board in one block (per-board NHWC input), for the small-batch path
 // (heads_board_dev, net_device.hpp).
-__global__ __launch_bounds__(512) void k_heads_board(HeadParams h, const float4* __restrict__ act,
+__global__ __launch_bounds__(1024) void k_heads_board(HeadParams h, const float4* __restrict__ act,
                                                      float* __restrict__ policy, float* __restrict__ value, int A,
                                                      int planes) {
-    extern __shared__ float s_hb[];
+    extern __shared__ __attribute__((aligned(16))) float s_hb[];
     const size_t board = blockIdx.x;
     heads_board_dev(h, act + board * A * (planes >> 2), policy + board * A, value + board, A, planes, s_hb);
 }
