@@ -310,6 +310,23 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             const float4* w4 = reinterpret_cast<const float4*>(layer == 0 ? n->conv0_w1 : n->conv_w[layer]);
             const bool timed = n->timing && layer > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
+            const bool use_h = nw == 9 && layer > 0 && h16_supported(n) && !getenv("AO_CELLS_F32");
+            if (use_h) {
+                switch (n->B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W:                                                                                                            \
+        hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid, block, 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],     \
+                           n->convh_wl[layer], reinterpret_cast<const float4*>(n->convh_sc[layer]),                    \
+                           reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res),   \
+                           reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0, n->d_status);                  \
+        break;
+                    AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+                    AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+                }
+                if (timed) timer_end(n, idx, s);
+                return;
+            }
             switch (n->B) {
 #define AO_CELLS_LAUNCH2(W, Q, NWV)                                                                           \
     hipLaunchKernelGGL((k_conv_cells<W, Q, NWV>), grid, block, 0, s, reinterpret_cast<const float4*>(in), w4, \
@@ -353,6 +370,10 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             unsigned long long h[8];
             hipStreamSynchronize(s);
             hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof_heads), sizeof(h));
+            unsigned long long cv[8];
+            hipMemcpyFromSymbol(cv, HIP_SYMBOL(ao_prof_conv), sizeof(cv));
+            fprintf(stderr, "AO_PROF k_conv_cells (last layer, block 0, wave 0) ticks: operands %llu, MFMAs %llu, barrier %llu, reduce+epilogue+store %llu, total %llu\n",
+                    cv[1] - cv[0], cv[2] - cv[1], cv[3] - cv[2], cv[4] - cv[3], cv[4] - cv[0]);
             fprintf(stderr, "AO_PROF k_heads_board ticks: w3 %llu, 1x1 conv %llu, reduce %llu, FC %llu, softmax+value %llu, tanh/store %llu, total %llu\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
         }

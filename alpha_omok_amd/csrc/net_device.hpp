@@ -43,19 +43,46 @@ __device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max
     return r;
 }
 
+#ifdef AO_PROF
+__device__ unsigned long long ao_prof_conv[8];    // k_conv_cells, block 0: wave 0 start / operands landed / MFMAs done / reduced / stored
+#define AO_CT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_conv[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long ao_prof_heads[8];   // phase ends of k_heads_board (thread 0 of board 0), shader-clock ticks
+#define AO_HT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_heads[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AO_HT(k)
+#define AO_CT(k)
+#endif
 // One (16 cells x 16 output channels) tile of one board's 3x3 conv, computed by NW waves:
 // each takes 9/NW taps (that share of the K loop), the partial tiles are summed through LDS.
 // A single wave per tile is bound by its own in-order chain of 144 loads; nine waves cut that
 // chain to 16 (best for one board), three to 48 (best for a few dozen).
 // Out-of-board taps are zero-filled per lane (cells of a tile differ in position).
 // All NW waves of the workgroup must call; s_red holds (NW-1) x 64 x 4 floats.
-template <int BW, int NCQG, int NW>
+// board rows a 16-cell tile's 3x3 neighbourhood can span, and the float4 slots of the LDS copy of those rows (one quad of
+// padding per cell: consecutive cells then start 16 bytes apart in the 256-byte bank window, so the 16 cells x 4 quads a
+// wave reads at once are conflict-free)
+__host__ __device__ constexpr int conv_cells_rows(int bw) {
+    return ((16 + bw - 2) / bw + 1 + 2) < bw ? ((16 + bw - 2) / bw + 1 + 2) : bw;
+}
+__host__ __device__ constexpr int conv_cells_lds_quads(int bw, int ncqg) { return conv_cells_rows(bw) * bw * (ncqg * 4 + 1); }
+
+// LDSX: the tile's board rows are copied to LDS once and the taps read their shifted views there (else every tap loads
+// its view from global memory: better when many small workgroups share a CU and LDS would limit them).
+// H16: the contraction runs on v_mfma_f32_16x16x32_f16 with split operands (x*w = xh*wh + xh*wl + xl*wh, fp32 accumulate,
+// as k_trunk16h): weights come pre-split (wh / wl: [tap][32-channel block][cout tile][lane] x 8 fp16, pre-scaled, `scale`
+// = the matching BatchNorm scale), the activations are split while they are read from LDS. Needs LDSX and planes % 32 == 0.
+typedef _Float16 cc_half8 __attribute__((ext_vector_type(8)));
+template <int BW, int NCQG, int NW, bool LDSX = true, bool H16 = false>
 __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                 const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                 const float4* res, float4* out, int CQI, int COUT, int relu_res,
-                                                int ct, int ctile, int board, float* s_red) {
+                                                int ct, int ctile, int board, float* s_red, float4* s_x,
+                                                const uint4* __restrict__ wh = nullptr, const uint4* __restrict__ wl = nullptr,
+                                                int* ovf = nullptr) {
+    static_assert(!H16 || (LDSX && NCQG % 2 == 0), "split-fp16 tiles read their activations from LDS, 32 channels per MFMA");
     constexpr int A = BW * BW;
     constexpr int TP = 9 / NW;
+    constexpr int QS = NCQG * 4 + 1;   // padded quads per cell in s_x
     const int lane = threadIdx.x & 63;
     const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     const int kq = lane >> 4, ci = lane & 15;
@@ -76,17 +103,61 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
         if (relu_res && cell < A) e_res = res[o_idx];
     }
     float4 rx[TP][NCQG], rw[TP][NCQG];
-    auto load_tap = [&](int tap, float4 (&X)[NCQG], float4 (&W)[NCQG]) {
+    // The nine taps of a tile read shifted views of the SAME few board rows. Loaded per tap from global memory that is
+    // 8 KB per wave and 72 KB per workgroup, as much as the weights, and the workgroup's 144 KB of operands through one
+    // CU's ~64 B/clk was most of the launch (AO_PROF: operands 3.1 k cycles for the first wave, the ninth another 2 k
+    // later, of 9 k in the kernel). The rows are now copied to LDS once (9x9, 128 planes: <= 45 cells = 23 KB) and the
+    // taps read their views there; only the weights still stream from L2.
+    const int c_lo = ctile * 16, c_hi = (c_lo + 15 < A ? c_lo + 15 : A - 1);
+    const int r0 = c_lo / BW > 0 ? c_lo / BW - 1 : 0;
+    const int r1 = c_hi / BW + 1 < BW ? c_hi / BW + 1 : BW - 1;
+    auto load_w = [&](int tap, float4 (&W)[NCQG]) {
+        const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
+#pragma unroll
+        for (int cqg = 0; cqg < NCQG; ++cqg) W[cqg] = wp[static_cast<size_t>(cqg) * 4 * COUT];
+    };
+    auto load_x = [&](int tap, float4 (&X)[NCQG]) {
         const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
         const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
-        const float4* xp = xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
-        const float4* wp = wt + (static_cast<size_t>(tap) * CQI + kq) * COUT + ct * 16 + ci;
+        const float4* xp = LDSX ? s_x + (ok ? (yy - r0) * BW + xx : 0) * QS + kq
+                                : xb + static_cast<size_t>(ok ? yy * BW + xx : 0) * CQI + kq;
 #pragma unroll
         for (int cqg = 0; cqg < NCQG; ++cqg) {
             float4 x = xp[cqg * 4];
             if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
             X[cqg] = x;
-            W[cqg] = wp[static_cast<size_t>(cqg) * 4 * COUT];
+        }
+    };
+    // split-fp16 form: per 32-channel block the lane's 8 channels (two quads) as high / low halves
+    constexpr int NC32 = H16 ? NCQG / 2 : 1;
+    cc_half8 xh[H16 ? TP : 1][NC32], xl[H16 ? TP : 1][NC32], whr[H16 ? TP : 1][NC32], wlr[H16 ? TP : 1][NC32];
+    float peak = 0.f;
+    auto load_w_h = [&](int j, int tap) {
+        const int nt = COUT >> 4;
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) {
+            const size_t idx = ((static_cast<size_t>(tap) * NC32 + c) * nt + ct) * 64 + lane;
+            whr[j][c] = __builtin_bit_cast(cc_half8, wh[idx]);
+            wlr[j][c] = __builtin_bit_cast(cc_half8, wl[idx]);
+        }
+    };
+    auto load_x_h = [&](int j, int tap) {
+        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
+        const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
+        const float4* xp = s_x + (ok ? (yy - r0) * BW + xx : 0) * QS + kq * 2;
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) {
+            float4 q0 = xp[c * 8], q1 = xp[c * 8 + 1];
+            if (!ok) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
+            const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                peak = fmaxf(peak, v[k]);
+                const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
+                const _Float16 hh = static_cast<_Float16>(t);
+                xh[j][c][k] = hh;
+                xl[j][c][k] = static_cast<_Float16>(t - static_cast<float>(hh));
+            }
         }
     };
     auto compute_tap = [&](const float4 (&X)[NCQG], const float4 (&W)[NCQG]) {
@@ -98,10 +169,47 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
             acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(W[cqg].w, X[cqg].w, acc3, 0, 0, 0);
         }
     };
+    AO_CT(0);
+    // weights first (they are not touched until the MFMAs), then this thread's share of the rows
 #pragma unroll
-    for (int j = 0; j < TP; ++j) load_tap(TP * w3 + j, rx[j], rw[j]);
+    for (int j = 0; j < TP; ++j) {
+        if (H16) load_w_h(j, TP * w3 + j);
+        else load_w(TP * w3 + j, rw[j]);
+    }
+    if (LDSX) {
+        const int nq = (r1 - r0 + 1) * BW * (NCQG * 4);
+        const float4* src = xb + static_cast<size_t>(r0) * BW * CQI;
+        for (int i = threadIdx.x; i < nq; i += NW * 64) {
+            const int c = i / (NCQG * 4), q = i - c * (NCQG * 4);
+            s_x[c * QS + q] = src[i];
+        }
+        __syncthreads();
+    }
 #pragma unroll
-    for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
+    for (int j = 0; j < TP; ++j) {
+        if (H16) load_x_h(j, TP * w3 + j);
+        else load_x(TP * w3 + j, rx[j]);
+    }
+#ifdef AO_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    AO_CT(1);
+    if (H16) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int c = 0; c < NC32; ++c) {
+                // four accumulator chains over the 32-channel blocks; hh, hl, lh of a block go to the same chain
+                f32x4& a = (c & 3) == 0 ? acc0 : (c & 3) == 1 ? acc1 : (c & 3) == 2 ? acc2 : acc3;
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j][c], xh[j][c], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j][c], xh[j][c], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j][c], xl[j][c], a, 0, 0, 0);
+            }
+        if (peak > 65504.f && ovf) atomicOr(ovf, 1);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
+    }
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
@@ -109,7 +217,9 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_red[((w3 - 1) * 64 + lane) * 4 + r] = acc[r];
     }
+    AO_CT(2);
     __syncthreads();
+    AO_CT(3);
     if (w3 == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -133,6 +243,10 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
             out[o] = v;
         }
     }
+#ifdef AO_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    AO_CT(4);
 }
 
 // LDS floats heads_board_dev needs
@@ -146,12 +260,7 @@ __host__ __device__ inline size_t heads_lds_floats(int A, int planes) {
 // slices so that all threads carry a short, independent chain of loads (the weight matrices come
 // from L2: 52 KB + 41 KB at 9x9), partial sums meet in LDS.
 // act = this board's activations [A][planes/4]; policy -> [A], value -> [1]. All threads must call.
-#ifdef AO_PROF
-__device__ unsigned long long ao_prof_heads[8];   // phase ends of k_heads_board (thread 0 of board 0), shader-clock ticks
-#define AO_HT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_heads[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define AO_HT(k)
-#endif
+
 __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float4* __restrict__ act,
                                                 float* __restrict__ policy, float* __restrict__ value, int A,
                                                 int planes, float* s_mem) {

@@ -18,7 +18,12 @@ template <int BW, int NCQG, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                    const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                    const float4* res, float4* out, int CQI, int COUT, int relu_res) {
+    // the tile's board rows in LDS for the one-tap-per-wave form (a handful of boards: one workgroup per CU anyway);
+    // the three-taps-per-wave form of larger batches keeps loading from global memory -- 24 KB of LDS per workgroup would
+    // cut the workgroups per CU from ten to six (16 games: 105 -> 142 us per simulation, measured)
+    constexpr bool LDSX = NW == 9;
     __shared__ float s_red[(NW - 1) * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float4 s_x[LDSX ? conv_cells_lds_quads(BW, NCQG) : 1];
     // 1-D grid with the output-channel tile fastest: workgroups are dispatched round-robin over
     // the 8 XCDs, so (for 8 tiles) XCD x only ever reads the weights of tile x -- 1/8 of the
     // network per L2, which then stays resident from one evaluation to the next (the whole net
@@ -27,7 +32,25 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
     const int ct = blockIdx.x % ntile;
     const int rest = blockIdx.x / ntile;
     constexpr int NCT = (BW * BW + 15) / 16;
-    conv_cells_tile<BW, NCQG, NW>(in, wt, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red);
+    conv_cells_tile<BW, NCQG, NW, LDSX, false>(in, wt, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red, s_x);
+}
+
+// The same tile on split-fp16 MFMAs (conv_cells_tile<..., H16>): 128-plane trunk layers of the one-tap-per-wave form. With
+// the activations coming from LDS the fp32 MFMAs of the nine waves (9 x 32 x 32 cycles on one CU's four matrix pipes)
+// were what was left of the launch; three 16-cycle fp16 MFMAs per 32-channel block replace eight 32-cycle fp32 ones.
+template <int BW, int NCQG>
+__global__ __launch_bounds__(64 * 9, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
+                                                            const uint4* __restrict__ wl, const float4* __restrict__ scale,
+                                                            const float4* __restrict__ shift, const float4* res, float4* out,
+                                                            int CQI, int COUT, int relu_res, int* ovf) {
+    __shared__ float s_red[8 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
+    const int ntile = COUT >> 4;
+    const int ct = blockIdx.x % ntile;
+    const int rest = blockIdx.x / ntile;
+    constexpr int NCT = (BW * BW + 15) / 16;
+    conv_cells_tile<BW, NCQG, 9, true, true>(in, nullptr, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red,
+                                              s_x, wh, wl, ovf);
 }
 
 
