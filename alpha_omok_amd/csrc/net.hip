@@ -315,7 +315,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                 switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W:                                                                                                            \
-        hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid, block, 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],     \
+        hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid, dim3(64 * 12), 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],     \
                            n->convh_wl[layer], reinterpret_cast<const float4*>(n->convh_sc[layer]),                    \
                            reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res),   \
                            reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0, n->d_status);                  \

@@ -81,7 +81,7 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
                                                 int* ovf = nullptr) {
     static_assert(!H16 || (LDSX && NCQG % 2 == 0), "split-fp16 tiles read their activations from LDS, 32 channels per MFMA");
     constexpr int A = BW * BW;
-    constexpr int TP = 9 / NW;
+    constexpr int TP = H16 ? 1 : 9 / NW;   // whole taps per wave (fp32 form)
     constexpr int QS = NCQG * 4 + 1;   // padded quads per cell in s_x
     const int lane = threadIdx.x & 63;
     const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -129,24 +129,26 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
         }
     };
     // split-fp16 form: per 32-channel block the lane's 8 channels (two quads) as high / low halves
+    // A work unit = (tap, 32-channel block): 9 x NC32 of them, NUH per wave, so that NW = 9 NC32 / NUH waves carry the same
+    // three MFMA triples each (128 planes: 36 units on 12 waves, three per SIMD -- with one tap per wave the SIMD that
+    // got three of the nine waves finished 1.5 k cycles after the others)
     constexpr int NC32 = H16 ? NCQG / 2 : 1;
-    cc_half8 xh[H16 ? TP : 1][NC32], xl[H16 ? TP : 1][NC32], whr[H16 ? TP : 1][NC32], wlr[H16 ? TP : 1][NC32];
+    constexpr int NUH = H16 ? (9 * NC32) / NW : 1;
+    static_assert(!H16 || NUH * NW == 9 * NC32, "split-fp16 tiles: the waves must divide the (tap, block) units evenly");
+    cc_half8 xh[NUH], xl[NUH], whr[NUH], wlr[NUH];
     float peak = 0.f;
-    auto load_w_h = [&](int j, int tap) {
+    auto load_w_h = [&](int j, int u) {
         const int nt = COUT >> 4;
-#pragma unroll
-        for (int c = 0; c < NC32; ++c) {
-            const size_t idx = ((static_cast<size_t>(tap) * NC32 + c) * nt + ct) * 64 + lane;
-            whr[j][c] = __builtin_bit_cast(cc_half8, wh[idx]);
-            wlr[j][c] = __builtin_bit_cast(cc_half8, wl[idx]);
-        }
+        const size_t idx = (static_cast<size_t>(u) * nt + ct) * 64 + lane;   // u = tap * NC32 + block
+        whr[j] = __builtin_bit_cast(cc_half8, wh[idx]);
+        wlr[j] = __builtin_bit_cast(cc_half8, wl[idx]);
     };
-    auto load_x_h = [&](int j, int tap) {
+    auto load_x_h = [&](int j, int u) {
+        const int tap = u / NC32, c = u - tap * NC32;
         const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
         const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
         const float4* xp = s_x + (ok ? (yy - r0) * BW + xx : 0) * QS + kq * 2;
-#pragma unroll
-        for (int c = 0; c < NC32; ++c) {
+        {
             float4 q0 = xp[c * 8], q1 = xp[c * 8 + 1];
             if (!ok) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
             const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -155,8 +157,8 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
                 peak = fmaxf(peak, v[k]);
                 const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
                 const _Float16 hh = static_cast<_Float16>(t);
-                xh[j][c][k] = hh;
-                xl[j][c][k] = static_cast<_Float16>(t - static_cast<float>(hh));
+                xh[j][k] = hh;
+                xl[j][k] = static_cast<_Float16>(t - static_cast<float>(hh));
             }
         }
     };
@@ -171,10 +173,12 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
     };
     AO_CT(0);
     // weights first (they are not touched until the MFMAs), then this thread's share of the rows
+    if (H16) {
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        if (H16) load_w_h(j, TP * w3 + j);
-        else load_w(TP * w3 + j, rw[j]);
+        for (int j = 0; j < NUH; ++j) load_w_h(j, NUH * w3 + j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) load_w(TP * w3 + j, rw[j]);
     }
     if (LDSX) {
         const int nq = (r1 - r0 + 1) * BW * (NCQG * 4);
@@ -185,10 +189,12 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
         }
         __syncthreads();
     }
+    if (H16) {
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        if (H16) load_x_h(j, TP * w3 + j);
-        else load_x(TP * w3 + j, rx[j]);
+        for (int j = 0; j < NUH; ++j) load_x_h(j, NUH * w3 + j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) load_x(TP * w3 + j, rx[j]);
     }
 #ifdef AO_PROF
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -196,15 +202,13 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
     AO_CT(1);
     if (H16) {
 #pragma unroll
-        for (int j = 0; j < TP; ++j)
-#pragma unroll
-            for (int c = 0; c < NC32; ++c) {
-                // four accumulator chains over the 32-channel blocks; hh, hl, lh of a block go to the same chain
-                f32x4& a = (c & 3) == 0 ? acc0 : (c & 3) == 1 ? acc1 : (c & 3) == 2 ? acc2 : acc3;
-                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j][c], xh[j][c], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j][c], xh[j][c], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j][c], xl[j][c], a, 0, 0, 0);
-            }
+        for (int j = 0; j < NUH; ++j) {
+            // one accumulator chain per unit (up to four); hh, hl, lh of a unit go to the same chain
+            f32x4& a = (j & 3) == 0 ? acc0 : (j & 3) == 1 ? acc1 : (j & 3) == 2 ? acc2 : acc3;
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xh[j], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j], xh[j], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xl[j], a, 0, 0, 0);
+        }
         if (peak > 65504.f && ovf) atomicOr(ovf, 1);
     } else {
 #pragma unroll

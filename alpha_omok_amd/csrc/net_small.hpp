@@ -39,17 +39,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
 // the activations coming from LDS the fp32 MFMAs of the nine waves (9 x 32 x 32 cycles on one CU's four matrix pipes)
 // were what was left of the launch; three 16-cycle fp16 MFMAs per 32-channel block replace eight 32-cycle fp32 ones.
 template <int BW, int NCQG>
-__global__ __launch_bounds__(64 * 9, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
+__global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
                                                             const uint4* __restrict__ wl, const float4* __restrict__ scale,
                                                             const float4* __restrict__ shift, const float4* res, float4* out,
                                                             int CQI, int COUT, int relu_res, int* ovf) {
-    __shared__ float s_red[8 * 64 * 4];
+    __shared__ float s_red[11 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
     const int ntile = COUT >> 4;
     const int ct = blockIdx.x % ntile;
     const int rest = blockIdx.x / ntile;
     constexpr int NCT = (BW * BW + 15) / 16;
-    conv_cells_tile<BW, NCQG, 9, true, true>(in, nullptr, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red,
+    conv_cells_tile<BW, NCQG, 12, true, true>(in, nullptr, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red,
                                               s_x, wh, wl, ovf);
 }
 
