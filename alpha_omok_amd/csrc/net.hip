@@ -184,7 +184,7 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     if (mode == 6) mode = 5;   // mode 6 = mode 5 restricted to the per-layer kernels (layers_only()): one arithmetic for every batch size
     if (mode == 0) {
         const long cells = static_cast<long>(boards) * n->A;
-        if (h16_supported(n)) mode = cells <= 3800 ? 3 : 5;
+        if (h16_supported(n)) mode = cells <= 4900 ? 3 : 5;   // (round 3: 60 9x9 boards -- 582 vs 513 move-decisions/s at 48 games, 637 vs 665 at 64, with the LDS + split-fp16 tile kernel)
         else mode = cells <= 13000 ? 3 : (g16 >= 192 ? 2 : 4);
     }
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
@@ -305,7 +305,10 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
         auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
-            const int nw = (boards <= 4) ? 9 : 3;
+            // one tap per wave (with the board rows in LDS) for up to four boards; 128-plane networks take that form -- as
+            // k_conv_cells_h, split-fp16 MFMAs -- for every batch of this path (6 ... 32 games: +10 ... +25 % over the
+            // three-taps-per-wave fp32 form, profiles/r3h_single_game_attempt.txt)
+            const int nw = (boards <= 4 || (h16_supported(n) && !getenv("AO_CELLS_F32"))) ? 9 : 3;
             const dim3 grid(((n->A + 15) / 16) * (n->planes / 16) * boards), block(64 * nw);
             const float4* w4 = reinterpret_cast<const float4*>(layer == 0 ? n->conv0_w1 : n->conv_w[layer]);
             const bool timed = n->timing && layer > 0;
@@ -932,7 +935,8 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
     std::string nm;
     double f;
     if (group == 1) {
-        nm = "k_conv_cells<" + bw + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
+        nm = h16_supported(n) ? "k_conv_cells_h<" + bw + ", 8> (one 3x3 conv, per-board NHWC, board rows in LDS, split-fp16 MFMA 16x16x32)"
+                              : "k_conv_cells<" + bw + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
         f = conv;
     } else if (group == 16 && mode == 4) {
         nm = "k_layer16<" + bw + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
