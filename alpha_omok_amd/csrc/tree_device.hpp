@@ -7,6 +7,12 @@
 #pragma once
 #include "engine_types.hpp"
 
+#ifdef AO_PROF
+static __device__ unsigned long long ao_prof_tree[16];   // game 0 of k_expand_select: phase ends (shader-clock ticks)
+#define AO_TT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_tree[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AO_TT(k)
+#endif
 namespace ao {
 
 // ----------------------------------------------------------------------------------------------
@@ -312,9 +318,11 @@ struct MtDev {
 // who made move j as they stood after move j. Written into the evaluation batch.
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
-__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s) {
+__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s, int row = -1) {
     const int lane = lane_id();
-    const int row = p.row_of_game ? p.row_of_game[g] : g;   // batch row of the native network (active games packed)
+    // batch row of the native network (active games packed); select_game requests it with the game header -- read here it was a
+    // dependent memory round trip at the very end of the kernel (AO_PROF: 1.7 k of the 5 k cycles after the descent)
+    if (row < 0) row = p.row_of_game ? p.row_of_game[g] : g;
     const int k = s.ply;
     const int stm = k & 1;           // 0: black to move
     const int C = p.C;
@@ -370,12 +378,14 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
 template <int NCH>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/) {
     const int lane = lane_id();
+    AO_TT(3);
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
     // overlap them with), so every step requests all it can in ONE trip: first the game header ...
     const int is_active = p.active ? p.active[g] : 1;
     const int done = p.sims_done[g], target = p.sims_target[g];
     const int arena = p.cur[g];
     int node = p.root_node[g];
+    const int batch_row = p.row_of_game ? p.row_of_game[g] : g;
     if (!is_active || done >= target) {
         if (lane == 0) p.leaf_status[g] = LS_IDLE;
         return;
@@ -391,6 +401,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         lp = pos_load(p.rootpos + g);
     } else {
         for (;;) {
+            AO_TT(4);
             const size_t slot = node_slot(p, arena, g, node);
             const size_t eb = slot * p.Ap;
             // ... then, per level, the node record together with all five edge rows. The rows are Ap
@@ -419,8 +430,11 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                 tot += n[c];
             }
             tot = wave_sum_i(tot);
-            // np.sqrt(total_n): correctly rounded table (total_n is an exact integer)
-            const double sq = p.sqrt_lut[tot < p.sqrt_lut_n ? tot : p.sqrt_lut_n - 1];
+            AO_TT(5);
+            // np.sqrt(total_n) (total_n is an exact integer): the device's correctly rounded double sqrt equals the host's for
+            // every integer below 2^24 (tools/sqrt_exact.hip, checked exhaustively on the MI355X) -- computed, not looked up: the
+            // table read depended on total_n and was one more memory round trip per level of the descent
+            const double sq = __dsqrt_rn(static_cast<double>(tot));
             double sc[NCH];
             double mx = -1.0e300;
 #pragma unroll
@@ -438,6 +452,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                 mx = sc[c] > mx ? sc[c] : mx;
             }
             mx = wave_max_d(mx);
+            AO_TT(6);
             // every exact-equal maximum, in child order; uniform pick (agents.py:161-163)
             uint64_t tm[NCH];
             int k = 0;
@@ -469,6 +484,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             }
             ++depth;
             ++levels;
+            AO_TT(7);
             int ch = CH_UNVISITED, a = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -490,19 +506,21 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             break;
         }
     }
+    AO_TT(8);
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         lp.nchild = 0;
         if (lane == 0) pos_store(p.leaf_pos + g, lp);
-        encode_planes<NCH>(p, g, lp);
+        encode_planes<NCH>(p, g, lp, batch_row);
     }
     if (lane == 0) {
         p.leaf_status[g] = status;
         p.path_len[g] = depth;
-        // per-game counters (a shared word would serialise 4 x G atomics per simulation)
+        // per-game counters (a shared word would serialise 4 x G atomics per simulation); no-return atomics: as plain
+        // read-modify-writes they were one more dependent round trip before the kernel could end
         unsigned* st = p.stats + static_cast<size_t>(g) * 4;
-        st[0] += levels;
-        st[1] += ties;
-        st[(status == LS_TERMINAL) ? 2 : 3] += 1u;
+        atomicAdd(st + 0, levels);
+        atomicAdd(st + 1, ties);
+        atomicAdd(st + ((status == LS_TERMINAL) ? 2 : 3), 1u);
     }
     mt.close();
 }

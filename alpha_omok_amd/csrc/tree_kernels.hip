@@ -53,9 +53,12 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     const int g = blockIdx.x * kGamesPerWG + w;
     if (g >= p.G) return;
+    AO_TT(0);
     expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w]);
     wsync();
+    AO_TT(1);
     select_game<NCH>(p, g, s_mt[w]);
+    AO_TT(2);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -403,6 +406,19 @@ void launch_expand_backup(const TreeParams& p, hipStream_t s) {
 }
 void launch_expand_select(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_expand_select<NCH>, dim3((p.G + kGamesPerWG - 1) / kGamesPerWG), dim3(64 * kGamesPerWG), 0, s, p));
+#ifdef AO_PROF
+    if (getenv("AO_PROF_TREE")) {
+        static int count = 0;
+        if (++count % 97 == 0) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof_tree), sizeof(h));
+            fprintf(stderr, "AO_PROF k_expand_select (game 0) ticks: expansion+backup %llu, selection+planes %llu | last level: header %llu rows %llu puct %llu "
+                    "tie+pick %llu child %llu | after loop: planes+stores %llu\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6],
+                    h[8] - h[7], h[2] - h[8]);
+        }
+    }
+#endif
 }
 void launch_begin_move(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_begin_move<NCH>, dim3(p.G), dim3(64), 0, s, p));
