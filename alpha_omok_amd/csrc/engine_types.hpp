@@ -12,6 +12,7 @@ constexpr int kBBWords = 4;        // 4 x u64 = 256 bits >= 15*15 cells
 constexpr int kMaxBoard = 15;
 constexpr int kMaxCells = kMaxBoard * kMaxBoard;
 constexpr int kLastMoves = 8;      // history kept for the input planes (C <= 9)
+constexpr int kMaxPlanes = 9;      // inplanes = 2 * history + 1 <= 9 (main.py:34)
 constexpr int kGroup = 32;         // boards per MFMA column group (32x32x2 f32 MFMA, N = boards)
 
 // A board position. bb[0] = black stones, bb[1] = white stones, bit index = row*B + col

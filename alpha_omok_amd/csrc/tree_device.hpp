@@ -329,33 +329,45 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
     // the last moves as one 64-bit word: byte i = move (ply - i); extracted with shifts (an indexed
     // byte array would live in scratch memory)
     const uint64_t last64 = s.last64;
+    // Plane q < C-1 is X_{k-j}, j = C-2-q: the stones of the player who made move k-j as they stood after it = that
+    // player's stones now minus his later moves k-j+2, k-j+4, ... (history entries j-2, j-4, ...). Built as a BITBOARD with
+    // wave-uniform operations (a colour's four words, a few bits cleared), so a cell only tests one bit per plane; computed per
+    // cell from the history this function was 4 k of the tree step's 20 k cycles for a single game (AO_PROF).
+    unsigned bits[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) bits[c] = 0u;
+#pragma unroll
+    for (int q = 0; q < kMaxPlanes - 1; ++q) {
+        const int j = C - 2 - q;
+        if (q >= C - 1 || k - j < 1) continue;   // (uniform)
+        const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
+        uint64_t w0 = col ? s.bb[1][0] : s.bb[0][0], w1 = col ? s.bb[1][1] : s.bb[0][1];
+        uint64_t w2 = col ? s.bb[1][2] : s.bb[0][2], w3 = col ? s.bb[1][3] : s.bb[0][3];
+#pragma unroll
+        for (int i = 0; i < kLastMoves; ++i) {
+            if (i >= j || ((j - i) & 1)) continue;   // same parity as j, below j
+            const int mv = static_cast<int>((last64 >> (8 * i)) & 0xFF);
+            if (mv == 0xFF) continue;
+            const uint64_t bit = 1ull << (mv & 63);
+            const int wi = mv >> 6;
+            w0 &= ~(wi == 0 ? bit : 0ull); w1 &= ~(wi == 1 ? bit : 0ull);
+            w2 &= ~(wi == 2 ? bit : 0ull); w3 &= ~(wi == 3 ? bit : 0ull);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int cell = lane + 64 * c;          // word c of the bitboard, bit `lane` (kBBWords == 4 >= NCH)
+            const uint64_t w = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;
+            bits[c] |= static_cast<unsigned>((w >> lane) & 1ull) << q;
+            (void)cell;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
         if (cell >= p.A) continue;
-        const unsigned own2 = (pos_test<0>(s, cell) ? 1u : 0u) | (pos_test<1>(s, cell) ? 2u : 0u);   // bit c: colour c has a stone here
-        // bit i set <=> this cell received move (ply - i)
-        unsigned recent = 0;
-#pragma unroll
-        for (int i = 0; i < kLastMoves; ++i) recent |= (static_cast<int>((last64 >> (8 * i)) & 0xFF) == cell) ? (1u << i) : 0u;
-        // plane q: q == C-1 colour; q < C-1: X_{k-j}, j = C-2-q -- the stones of the player who made move
-        // k-j as they stood after it: that player's stones now, minus his moves k-j+2, k-j+4, ... (the last
-        // j-2, j-4, ... entries of the history, same parity as j)
-        auto plane = [&](int q) -> float {
-            if (q >= C) return 0.f;
-            if (q == C - 1) return (stm == 0) ? 1.f : 0.f;
-            const int j = C - 2 - q;
-            if (k - j < 1) return 0.f;
-            const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
-            // later moves of the same player: history entries j-2, j-4, ..., i.e. bits of `recent` below j with j's parity
-            const unsigned later = recent & ((1u << j) - 1u) & ((j & 1) ? 0xAAu : 0x55u);
-            return (((own2 >> col) & 1u) && later == 0u) ? 1.f : 0.f;
-        };
-        if (p.batch_u8) {
-            unsigned bits = 0;
-            for (int q = 0; q < C; ++q) bits |= (plane(q) != 0.f) ? (1u << q) : 0u;
-            p.batch_u8[static_cast<size_t>(row) * p.u8_row + cell] = static_cast<uint8_t>(bits);
-        }
+        const unsigned bq = bits[c] | ((stm == 0) ? (1u << (C - 1)) : 0u);   // + the colour plane
+        auto plane = [&](int q) -> float { return (q < C && ((bq >> q) & 1u)) ? 1.f : 0.f; };
+        if (p.batch_u8) p.batch_u8[static_cast<size_t>(row) * p.u8_row + cell] = static_cast<uint8_t>(bq & ((1u << C) - 1u));
         if (p.batch_nchw) {
             for (int q = 0; q < C; ++q) p.batch_nchw[(static_cast<size_t>(g) * C + q) * p.A + cell] = plane(q);
         }
@@ -510,8 +522,10 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         lp.nchild = 0;
         if (lane == 0) pos_store(p.leaf_pos + g, lp);
+        AO_TT(9);
         encode_planes<NCH>(p, g, lp, batch_row);
     }
+    AO_TT(10);
     if (lane == 0) {
         p.leaf_status[g] = status;
         p.path_len[g] = depth;
@@ -522,6 +536,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         atomicAdd(st + 1, ties);
         atomicAdd(st + ((status == LS_TERMINAL) ? 2 : 3), 1u);
     }
+    AO_TT(11);
     mt.close();
 }
 

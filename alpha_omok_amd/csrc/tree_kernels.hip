@@ -414,8 +414,8 @@ void launch_expand_select(const TreeParams& p, hipStream_t s) {
             (void)hipStreamSynchronize(s);
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof_tree), sizeof(h));
             fprintf(stderr, "AO_PROF k_expand_select (game 0) ticks: expansion+backup %llu, selection+planes %llu | last level: header %llu rows %llu puct %llu "
-                    "tie+pick %llu child %llu | after loop: planes+stores %llu\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6],
-                    h[8] - h[7], h[2] - h[8]);
+                    "tie+pick %llu child %llu | after loop: pos_store %llu planes %llu status+counters %llu mt.close %llu\n", h[1] - h[0], h[2] - h[1], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6],
+                    h[8] - h[7], h[9] - h[8], h[10] - h[9], h[11] - h[10], h[2] - h[11]);
         }
     }
 #endif
