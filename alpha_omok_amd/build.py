@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libomok_hip.so")
-SOURCES = ["tree_kernels.hip", "engine.hip", "net.hip", "replay.hip", "rollout.hip"]
+SOURCES = ["tree_kernels.hip", "step_kernels.hip", "engine.hip", "net.hip", "replay.hip", "rollout.hip"]
 HEADERS = ["engine_types.hpp", "host_rng.hpp", "tree_device.hpp", "net_device.hpp", "net_common.hpp", "net_trunk_f32.hpp",
            "net_trunk_h16.hpp", "net_small.hpp", os.path.join(INC, "omok_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -33,7 +33,10 @@ void launch_walk(const TreeParams& p, int count, const int32_t* games, const int
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 // net.hip
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
-                   hipStream_t s, int in_kind);
+                   hipStream_t s, int in_kind, int parts);
+int net_step_params(ao_net* n, int boards, float* policy, float* value, StepNet* out);
+// step_kernels.hip
+void launch_step_board(const TreeParams& p, const StepNet& f, int rows, const int32_t* game_of_row, hipStream_t s);
 void net_plan(const ao_net* n, int boards, int* group, int* nchq, int* kind);
 int net_check(const ao_net* n, int board, int inplanes, int device, std::string* why);
 }  // namespace ao
@@ -54,7 +57,7 @@ struct ao_engine {
     std::vector<int32_t> h_walk;     // staging of ao_set_root(s): [G][A] moves + games, counts, prev_known, status
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
     uint8_t* d_planes_u8 = nullptr;                       // bit planes [Gp][u8_row] (input of the split-fp16 kernels)
-    int32_t* d_row = nullptr;                             // [G] batch row of each game in ao_search (active games packed)
+    int32_t* d_row = nullptr;                             // [2G] batch row of each game in ao_search (active games packed), then the game of each row
     std::vector<int32_t> h_row;
     size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
@@ -229,7 +232,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &e->d_policy, static_cast<size_t>(Gp) * A) || dev_alloc(e, &e->d_value, Gp))
         return 1;
     p.u8_row = A <= 128 ? 128 : 256;
-    if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, G)) return 1;
+    if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, 2 * static_cast<size_t>(G))) return 1;
     if (dev_alloc(e, &e->d_mt_backup, static_cast<size_t>(G) * 624) || dev_alloc(e, &e->d_pos_backup, G)) return 1;
     p.row_of_game = nullptr;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
@@ -639,11 +642,14 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // a move in which a third of the slots still plays -- the tail of main.self_play(n), one side of evaluate_batched,
     // an uneven shard -- costs a third of the network time, and may take another kernel (net_plan for that many boards).
     int rows = 0;
-    e->h_row.assign(e->G, 0);
+    e->h_row.assign(2 * static_cast<size_t>(e->G), 0);
     for (int g = 0; g < e->G; ++g)
-        if (e->active[g]) e->h_row[g] = rows++;
+        if (e->active[g]) {
+            e->h_row[e->G + rows] = g;
+            e->h_row[g] = rows++;
+        }
     if (rows == 0) return ao_end_move(e, tau, pi, visit, policy);
-    AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * e->G, hipMemcpyHostToDevice, e->stream));
+    AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * 2 * e->G, hipMemcpyHostToDevice, e->stream));
     int in_kind = 1;
     ao::net_plan(net, rows, &e->tp.il_group, &e->tp.nchq, &in_kind);
     // The padding channels of the fp32 input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
@@ -670,14 +676,21 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         p.batch_u8 = e->d_planes_u8;
         p.batch_il = nullptr;
     }
+    // A few games (the per-board network path): heads, tree step and the next leaf's conv1 are ONE launch per game
+    // (k_step_board), the network is asked for the residual blocks alone -- 9 launches per simulation instead of 11.
+    ao::StepNet step{};
+    const bool fused = ao::net_step_params(net, rows, e->d_policy, e->d_value, &step) != 0;
+    bool first_sim = true;
     auto one_sim = [&]() -> int {
-        if (ao::net_forward_il(net, net_in, rows, e->d_policy, e->d_value, e->stream, in_kind))
+        if (ao::net_forward_il(net, net_in, rows, e->d_policy, e->d_value, e->stream, in_kind, fused ? (first_sim ? 3 : 2) : 7))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
+        first_sim = false;
         if (e->timing) {
             if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);
             (void)hipEventRecord(e->ev0[e->ring_head], e->stream);
         }
-        ao::launch_expand_select(p, e->stream);
+        if (fused) ao::launch_step_board(p, step, rows, e->d_row + e->G, e->stream);
+        else ao::launch_expand_select(p, e->stream);
         if (e->timing) {
             (void)hipEventRecord(e->ev1[e->ring_head], e->stream);
             e->ring_head = (e->ring_head + 1) % ao_engine::kRing;

@@ -94,4 +94,32 @@ __host__ __device__ inline size_t node_slot(const TreeParams& p, int arena, int 
     return (static_cast<size_t>(arena) * p.G + g) * p.cap + node;
 }
 
+// parameters of both heads (model.py:34-73); BatchNorm folded into sc3/sh3
+struct HeadParams {
+    const float* w3;    // [3][planes]   1x1 convs: 2 policy channels + 1 value channel
+    const float* sc3;   // [3]
+    const float* sh3;   // [3]
+    const float* wp_t;  // [2A][A]       policy_fc weight, transposed (input-major)
+    const float* bp;    // [A]
+    const float* w1_t;  // [A][planes]   value_fc1 weight, transposed
+    const float* b1;    // [planes]
+    const float* w2;    // [planes]      value_fc2
+    const float* b2;    // [1]
+};
+
+// What the fused per-game step (k_step_board, step_kernels.hip: heads of the last leaf -> expansion + backup + selection ->
+// conv1 of the new leaf, one workgroup per game) needs from the network of the per-board path.
+struct StepNet {
+    HeadParams heads;
+    float* act;            // [rows][A][planes] fp32: the trunk's output (read by the heads) AND conv1's output (written)
+    float* policy;         // [rows][A]
+    float* value;          // [rows]
+    const uint4* w1h;      // conv1 weights, split fp16, K = tap * 8 + plane padded to 96: [k step 3][cout tile][lane 64] x 8 halves
+    const uint4* w1l;
+    const float* sc1;      // [planes] BatchNorm scale / weight pre-scale
+    const float* sh1;      // [planes]
+    int planes;
+    int C;
+};
+
 }  // namespace ao

@@ -49,6 +49,7 @@ struct ao_net {
     // split-fp16 trunk (mode 5): per trunk conv after conv1 the high / low weight halves (pre-scaled by a
     // power of two) and the BatchNorm scale with that power of two folded back
     std::vector<uint4*> convh_wh, convh_wl;
+    uint4 *step_w1h = nullptr, *step_w1l = nullptr;   // conv1 for the fused per-game step (StepNet): K = tap * 8 + plane, padded to 96
     std::vector<float*> convh_sc;
     float* conv0_w16 = nullptr;                    // conv1 weights packed for nchq16
     float* conv0_w1 = nullptr;                     // conv1 weights packed for nchq1 (per-board NHWC path)
@@ -291,7 +292,31 @@ static HeadParams head_params(const ao_net* n) {
 
 // in_il: interleaved batch in the layout net_plan(n, boards) announced. policy/value must have
 // room for `boards` rounded up to the plan's group size.
-int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s, int in_kind) {
+// The fused per-game step (step_kernels.hip) is available when this batch takes the per-board path with the split-fp16 tiles:
+// fills `out` (heads, conv1 in its K = tap * C + plane form, the trunk buffer) and returns 1, else 0. AO_FUSED_STEP=0 turns it off.
+int net_step_params(ao_net* n, int boards, float* policy, float* value, StepNet* out) {
+    if (!n->finalized || !n->step_w1h || !h16_supported(n) || getenv("AO_CELLS_F32")) return 0;
+    if (const char* v = getenv("AO_FUSED_STEP")) if (atoi(v) == 0) return 0;
+    int group = 0, nchq = 0;
+    net_plan(n, boards, &group, &nchq, nullptr);
+    if (group != 1) return 0;
+    if (hipSetDevice(n->device) != hipSuccess || ensure_workspace(n, boards)) return 0;
+    out->heads = head_params(n);
+    out->act = n->act_x;
+    out->policy = policy;
+    out->value = value;
+    out->w1h = n->step_w1h;
+    out->w1l = n->step_w1l;
+    out->sc1 = n->convh_sc[0];
+    out->sh1 = n->conv_sh[0];
+    out->planes = n->planes;
+    out->C = n->C;
+    return 1;
+}
+
+// parts (per-board path only): 1 = conv1, 2 = the residual blocks, 4 = the heads -- the fused per-game step (k_step_board)
+// computes conv1 and the heads itself and asks for the blocks alone.
+int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s, int in_kind, int parts) {
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
@@ -302,6 +327,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     if (in_kind == 2 && !(mode == 5 && n->C <= 8)) return n->fail("bit planes handed to a kernel that takes the fp32 batch");
     n->last_in_kind = in_kind == 2 ? 2 : 1;
     const int groups = (boards + group - 1) / group;
+    if (group != 1 && parts != 7) return n->fail("a partial forward exists on the per-board path only");
     if (group == 1) {
         // per-board NHWC path: one wave per (16 cells, 16 couts, board)
         auto conv = [&](int layer, const float* in, int cqi, const float* res, float* out) {
@@ -315,13 +341,20 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             const int idx = timed ? timer_begin(n, s) : 0;
             const bool use_h = nw == 9 && layer > 0 && h16_supported(n) && !getenv("AO_CELLS_F32");
             if (use_h) {
+                // boards per workgroup: the weights are loaded once per workgroup, so as many boards as still leave every CU
+                // about three workgroups
+                const int ntl = ((n->A + 15) / 16) * (n->planes / 16);
+                int bpw = static_cast<int>((static_cast<long>(boards) * ntl) / (static_cast<long>(n->num_cu) * 3));
+                if (const char* v = getenv("AO_BPW")) bpw = atoi(v);
+                bpw = std::max(1, std::min(bpw, boards));
+                const dim3 grid_h(ntl * ((boards + bpw - 1) / bpw));
                 switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W:                                                                                                            \
-        hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid, dim3(64 * 12), 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],     \
+        hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid_h, dim3(64 * 12), 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],   \
                            n->convh_wl[layer], reinterpret_cast<const float4*>(n->convh_sc[layer]),                    \
                            reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res),   \
-                           reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0, n->d_status);                  \
+                           reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0, n->d_status, boards, bpw);     \
         break;
                     AO_BW_CASE(3) AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
                     AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
@@ -359,14 +392,15 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             }
             if (timed) timer_end(n, idx, s);
         };
-        conv(0, in_il, n->nchq1, nullptr, n->act_x);
-        for (int i = 0; i < n->nb; ++i) {
+        if (parts & 1) conv(0, in_il, n->nchq1, nullptr, n->act_x);
+        for (int i = 0; i < n->nb && (parts & 2); ++i) {
             conv(1 + 2 * i, n->act_x, n->CQ, nullptr, n->act_t);
             conv(2 + 2 * i, n->act_t, n->CQ, n->act_x, n->act_x);
         }
         const size_t lds1 = heads_lds_floats(n->A, n->planes) * sizeof(float);
-        hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(1024), lds1, s, head_params(n),
-                           reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
+        if (parts & 4)
+            hipLaunchKernelGGL(k_heads_board, dim3(boards), dim3(1024), lds1, s, head_params(n),
+                               reinterpret_cast<const float4*>(n->act_x), policy, value, n->A, n->planes);
         NET_HIP(n, hipGetLastError());
 #ifdef AO_PROF
         if (getenv("AO_PROF_PRINT")) {
@@ -832,6 +866,31 @@ int ao_net_finalize(ao_net* n) {
             n->convh_sc.push_back(dsc);
         }
     }
+    n->step_w1h = n->step_w1l = nullptr;
+    if (h16 && n->C <= 8) {
+        // conv1 once more for the fused per-game step: the contraction index k = tap * 8 + plane (three 32-deep MFMA steps
+        // instead of one per tap; a lane's 8 values are the planes of one neighbour cell), same pre-scale as convh_wh[0]
+        const int nt = P / 16;
+        std::vector<uint16_t> hi(static_cast<size_t>(3) * nt * 64 * 8, 0), lo(hi.size(), 0);
+        const float scale = std::ldexp(1.0f, pk[0].sft);
+        for (int co = 0; co < P; ++co)
+            for (int c = 0; c < n->C; ++c)
+                for (int t = 0; t < 9; ++t) {
+                    const float v = (*pk[0].w)[(static_cast<size_t>(co) * n->C + c) * 9 + t] * scale;
+                    const _Float16 h = static_cast<_Float16>(v);
+                    const _Float16 l = static_cast<_Float16>(v - static_cast<float>(h));
+                    const int kk = t * 8 + c;
+                    const size_t idx = ((((static_cast<size_t>(kk / 32) * nt + co / 16) * 4 + (kk % 32) / 8) * 16 + co % 16) * 8) + kk % 8;
+                    std::memcpy(&hi[idx], &h, 2);
+                    std::memcpy(&lo[idx], &l, 2);
+                }
+        uint16_t *dh = nullptr, *dl = nullptr;
+        if (param_alloc(n, &dh, hi.size()) || param_alloc(n, &dl, lo.size())) return 1;
+        NET_HIP(n, hipMemcpy(dh, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+        NET_HIP(n, hipMemcpy(dl, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+        n->step_w1h = reinterpret_cast<uint4*>(dh);
+        n->step_w1l = reinterpret_cast<uint4*>(dl);
+    }
     // heads
     const std::vector<float>*pw, *vw, *fcw, *fcb, *f1w, *f1b, *f2w, *f2b;
     if (get_param(n, "policy_head.policy_head.weight", 2 * P, &pw) ||
@@ -879,7 +938,7 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
     const size_t total = static_cast<size_t>(boards) * n->A;
     hipLaunchKernelGGL(ao::k_nchw_to_il, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
                        dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, nchq, boards, group);
-    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s, 1)) return 1;
+    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s, 1, 7)) return 1;
     if (boards != batch) {
         NET_HIP(n, hipMemcpyAsync(dev_policy, n->tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s));
         NET_HIP(n, hipMemcpyAsync(dev_value, n->tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s));

@@ -11,22 +11,12 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "engine_types.hpp"
+
 namespace ao {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// parameters of both heads (model.py:34-73); BatchNorm folded into sc3/sh3
-struct HeadParams {
-    const float* w3;    // [3][planes]   1x1 convs: 2 policy channels + 1 value channel
-    const float* sc3;   // [3]
-    const float* sh3;   // [3]
-    const float* wp_t;  // [2A][A]       policy_fc weight, transposed (input-major)
-    const float* bp;    // [A]
-    const float* w1_t;  // [A][planes]   value_fc1 weight, transposed
-    const float* b1;    // [planes]
-    const float* w2;    // [planes]      value_fc2
-    const float* b2;    // [1]
-};
 
 __device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -68,20 +58,14 @@ __host__ __device__ constexpr int conv_cells_lds_quads(int bw, int ncqg) { retur
 
 // LDSX: the tile's board rows are copied to LDS once and the taps read their shifted views there (else every tap loads
 // its view from global memory: better when many small workgroups share a CU and LDS would limit them).
-// H16: the contraction runs on v_mfma_f32_16x16x32_f16 with split operands (x*w = xh*wh + xh*wl + xl*wh, fp32 accumulate,
-// as k_trunk16h): weights come pre-split (wh / wl: [tap][32-channel block][cout tile][lane] x 8 fp16, pre-scaled, `scale`
-// = the matching BatchNorm scale), the activations are split while they are read from LDS. Needs LDSX and planes % 32 == 0.
 typedef _Float16 cc_half8 __attribute__((ext_vector_type(8)));
-template <int BW, int NCQG, int NW, bool LDSX = true, bool H16 = false>
+template <int BW, int NCQG, int NW, bool LDSX = true>
 __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, const float4* __restrict__ wt,
                                                 const float4* __restrict__ scale, const float4* __restrict__ shift,
                                                 const float4* res, float4* out, int CQI, int COUT, int relu_res,
-                                                int ct, int ctile, int board, float* s_red, float4* s_x,
-                                                const uint4* __restrict__ wh = nullptr, const uint4* __restrict__ wl = nullptr,
-                                                int* ovf = nullptr) {
-    static_assert(!H16 || (LDSX && NCQG % 2 == 0), "split-fp16 tiles read their activations from LDS, 32 channels per MFMA");
+                                                int ct, int ctile, int board, float* s_red, float4* s_x) {
     constexpr int A = BW * BW;
-    constexpr int TP = H16 ? 1 : 9 / NW;   // whole taps per wave (fp32 form)
+    constexpr int TP = 9 / NW;   // whole taps per wave
     constexpr int QS = NCQG * 4 + 1;   // padded quads per cell in s_x
     const int lane = threadIdx.x & 63;
     const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -128,40 +112,6 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
             X[cqg] = x;
         }
     };
-    // split-fp16 form: per 32-channel block the lane's 8 channels (two quads) as high / low halves
-    // A work unit = (tap, 32-channel block): 9 x NC32 of them, NUH per wave, so that NW = 9 NC32 / NUH waves carry the same
-    // three MFMA triples each (128 planes: 36 units on 12 waves, three per SIMD -- with one tap per wave the SIMD that
-    // got three of the nine waves finished 1.5 k cycles after the others)
-    constexpr int NC32 = H16 ? NCQG / 2 : 1;
-    constexpr int NUH = H16 ? (9 * NC32) / NW : 1;
-    static_assert(!H16 || NUH * NW == 9 * NC32, "split-fp16 tiles: the waves must divide the (tap, block) units evenly");
-    cc_half8 xh[NUH], xl[NUH], whr[NUH], wlr[NUH];
-    float peak = 0.f;
-    auto load_w_h = [&](int j, int u) {
-        const int nt = COUT >> 4;
-        const size_t idx = (static_cast<size_t>(u) * nt + ct) * 64 + lane;   // u = tap * NC32 + block
-        whr[j] = __builtin_bit_cast(cc_half8, wh[idx]);
-        wlr[j] = __builtin_bit_cast(cc_half8, wl[idx]);
-    };
-    auto load_x_h = [&](int j, int u) {
-        const int tap = u / NC32, c = u - tap * NC32;
-        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
-        const bool ok = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
-        const float4* xp = s_x + (ok ? (yy - r0) * BW + xx : 0) * QS + kq * 2;
-        {
-            float4 q0 = xp[c * 8], q1 = xp[c * 8 + 1];
-            if (!ok) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
-            const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                peak = fmaxf(peak, v[k]);
-                const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
-                const _Float16 hh = static_cast<_Float16>(t);
-                xh[j][k] = hh;
-                xl[j][k] = static_cast<_Float16>(t - static_cast<float>(hh));
-            }
-        }
-    };
     auto compute_tap = [&](const float4 (&X)[NCQG], const float4 (&W)[NCQG]) {
 #pragma unroll
         for (int cqg = 0; cqg < NCQG; ++cqg) {
@@ -173,13 +123,8 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
     };
     AO_CT(0);
     // weights first (they are not touched until the MFMAs), then this thread's share of the rows
-    if (H16) {
 #pragma unroll
-        for (int j = 0; j < NUH; ++j) load_w_h(j, NUH * w3 + j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < TP; ++j) load_w(TP * w3 + j, rw[j]);
-    }
+    for (int j = 0; j < TP; ++j) load_w(TP * w3 + j, rw[j]);
     if (LDSX) {
         const int nq = (r1 - r0 + 1) * BW * (NCQG * 4);
         const float4* src = xb + static_cast<size_t>(r0) * BW * CQI;
@@ -189,31 +134,14 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
         }
         __syncthreads();
     }
-    if (H16) {
 #pragma unroll
-        for (int j = 0; j < NUH; ++j) load_x_h(j, NUH * w3 + j);
-    } else {
-#pragma unroll
-        for (int j = 0; j < TP; ++j) load_x(TP * w3 + j, rx[j]);
-    }
+    for (int j = 0; j < TP; ++j) load_x(TP * w3 + j, rx[j]);
 #ifdef AO_PROF
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
     AO_CT(1);
-    if (H16) {
 #pragma unroll
-        for (int j = 0; j < NUH; ++j) {
-            // one accumulator chain per unit (up to four); hh, hl, lh of a unit go to the same chain
-            f32x4& a = (j & 3) == 0 ? acc0 : (j & 3) == 1 ? acc1 : (j & 3) == 2 ? acc2 : acc3;
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xh[j], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j], xh[j], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xl[j], a, 0, 0, 0);
-        }
-        if (peak > 65504.f && ovf) atomicOr(ovf, 1);
-    } else {
-#pragma unroll
-        for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
-    }
+    for (int j = 0; j < TP; ++j) compute_tap(rx[j], rw[j]);
     f32x4 acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
@@ -253,6 +181,129 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
     AO_CT(4);
 }
 
+// The tile on v_mfma_f32_16x16x32_f16 with split operands (x*w = xh*wh + xh*wl + xl*wh, fp32 accumulate, as k_trunk16h):
+// weights come pre-split (wh / wl: [tap][32-channel block][cout tile][lane] x 8 fp16, pre-scaled, `scale` = the matching
+// BatchNorm scale), the activations are split while they are read from LDS. A work unit = (tap, 32-channel block): 9 x NC32
+// of them, NUH per wave (128 planes: 36 units on 12 waves, three MFMA triples each and three waves per SIMD -- with one tap
+// per wave the SIMD that got three of the nine waves finished 1.5 k cycles after the others).
+// It serves SEVERAL boards in turn (k_conv_cells_h): a workgroup owns one (16 cells x 16 channels) tile position
+// and walks `nb` boards with it. The wave's weights -- three (tap, 32-channel block) units, high and low halves, 24
+// registers -- are loaded ONCE; per board only the tile's board rows (23 KB at 9x9) come through the CU. One workgroup per
+// board and tile re-pulled the 72 KB of weights for every board: fine for a handful of games, L2-bound for a hundred.
+// s_red holds two buffers of (NW - 1) x 64 x 4 floats (alternating per board, so a wave may write the next board's partial
+// sums while wave 0 still adds up this board's).
+template <int BW, int NCQG, int NW>
+__device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in, const uint4* __restrict__ wh, const uint4* __restrict__ wl,
+                                                  const float4* __restrict__ scale, const float4* __restrict__ shift, const float4* res,
+                                                  float4* out, int CQI, int COUT, int relu_res, int ct, int ctile, int board0, int nb,
+                                                  float* s_red, float4* s_x, int* ovf) {
+    constexpr int A = BW * BW;
+    constexpr int QS = NCQG * 4 + 1;
+    constexpr int NC32 = NCQG / 2;
+    constexpr int NUH = (9 * NC32) / NW;
+    static_assert(NUH * NW == 9 * NC32 && NCQG % 2 == 0, "the waves must divide the (tap, 32-channel block) units evenly");
+    const int lane = threadIdx.x & 63;
+    const int w3 = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int kq = lane >> 4, ci = lane & 15;
+    const int cell = ctile * 16 + ci;
+    const int cy = cell / BW, cx = cell - cy * BW;
+    const int c_lo = ctile * 16, c_hi = (c_lo + 15 < A ? c_lo + 15 : A - 1);
+    const int r0 = c_lo / BW > 0 ? c_lo / BW - 1 : 0;
+    const int r1 = c_hi / BW + 1 < BW ? c_hi / BW + 1 : BW - 1;
+    const int cqo = ct * 4 + kq;
+    AO_CT(0);
+    // once per workgroup: this wave's weights and the epilogue's scale / shift
+    cc_half8 whr[NUH], wlr[NUH];
+    {
+        const int nt = COUT >> 4;
+#pragma unroll
+        for (int j = 0; j < NUH; ++j) {
+            const size_t idx = (static_cast<size_t>(NUH * w3 + j) * nt + ct) * 64 + lane;   // unit = tap * NC32 + block
+            whr[j] = __builtin_bit_cast(cc_half8, wh[idx]);
+            wlr[j] = __builtin_bit_cast(cc_half8, wl[idx]);
+        }
+    }
+    float4 e_sc = make_float4(0.f, 0.f, 0.f, 0.f), e_sh = e_sc;
+    if (w3 == 0) { e_sc = scale[cqo]; e_sh = shift[cqo]; }
+    // per unit: where this lane's B operand sits in the LDS copy of the rows (the same for every board)
+    int xoff[NUH];
+    bool xok[NUH];
+#pragma unroll
+    for (int j = 0; j < NUH; ++j) {
+        const int u = NUH * w3 + j, tap = u / NC32, c = u - tap * NC32;
+        const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
+        xok[j] = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
+        xoff[j] = (xok[j] ? (yy - r0) * BW + xx : 0) * QS + kq * 2 + c * 8;
+    }
+    const int nq = (r1 - r0 + 1) * BW * (NCQG * 4);
+    float peak = 0.f;
+    for (int bi = 0; bi < nb; ++bi) {
+        const int board = board0 + bi;
+        const size_t o_idx = (static_cast<size_t>(board) * A + (cell < A ? cell : 0)) * (COUT >> 2) + cqo;
+        float4 e_res = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w3 == 0 && relu_res && cell < A) e_res = res[o_idx];
+        // the tile's board rows of this board into LDS (every wave has finished reading the previous board's: they all
+        // passed the reduction barrier below after their LDS reads)
+        {
+            const float4* src = in + (static_cast<size_t>(board) * A + static_cast<size_t>(r0) * BW) * CQI;
+            for (int i = threadIdx.x; i < nq; i += NW * 64) {
+                const int c = i / (NCQG * 4), q = i - c * (NCQG * 4);
+                s_x[c * QS + q] = src[i];
+            }
+        }
+        __syncthreads();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll
+        for (int j = 0; j < NUH; ++j) {
+            float4 q0 = s_x[xoff[j]], q1 = s_x[xoff[j] + 1];
+            if (!xok[j]) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
+            const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            cc_half8 xh, xl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                peak = fmaxf(peak, v[k]);
+                const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
+                const _Float16 hh = static_cast<_Float16>(t);
+                xh[k] = hh;
+                xl[k] = static_cast<_Float16>(t - static_cast<float>(hh));
+            }
+            // one accumulator chain per unit (up to four); hh, hl, lh of a unit go to the same chain
+            f32x4& a = (j & 3) == 0 ? acc0 : (j & 3) == 1 ? acc1 : (j & 3) == 2 ? acc2 : acc3;
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xh, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j], xh, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xl, a, 0, 0, 0);
+        }
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+        float* red = s_red + (bi & 1) * (NW - 1) * 64 * 4;
+        if (w3 > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((w3 - 1) * 64 + lane) * 4 + r] = acc[r];
+        }
+        __syncthreads();
+        if (w3 == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[r];
+#pragma unroll
+                for (int k = 0; k < NW - 1; ++k) t += red[(k * 64 + lane) * 4 + r];
+                acc[r] = t;
+            }
+            if (cell < A) {   // D row = cout 4*kq + reg, col = cell ci
+                float4 v;
+                v.x = fmaf(acc[0], e_sc.x, e_sh.x); v.y = fmaf(acc[1], e_sc.y, e_sh.y);
+                v.z = fmaf(acc[2], e_sc.z, e_sh.z); v.w = fmaf(acc[3], e_sc.w, e_sh.w);
+                if (relu_res) { v.x += e_res.x; v.y += e_res.y; v.z += e_res.z; v.w += e_res.w; }
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                out[o_idx] = v;
+            }
+        }
+    }
+    if (peak > 65504.f && ovf) atomicOr(ovf, 1);
+    AO_CT(4);
+}
+
 // LDS floats heads_board_dev needs
 __host__ __device__ inline size_t heads_lds_floats(int A, int planes) {
     return static_cast<size_t>(3) * planes + 3 * A + 36 * A + 6 * A + 4 * planes + planes + 16;
@@ -279,7 +330,7 @@ __device__ __forceinline__ void heads_board_dev(const HeadParams& h, const float
     float* s_part = s_hp + KS * 3 * A;   // [NPS][A]
     float* s_vpart = s_part + NPS * A;   // [NVS][planes]
     float* s_hid = s_vpart + NVS * planes;  // [planes]
-    float* s_red = s_hid + planes;       // [16]
+    (void)(s_hid + planes);              // [16] spare
     const int tid = threadIdx.x, nt = blockDim.x;
     const int CQ = planes >> 2;
     AO_HT(0);

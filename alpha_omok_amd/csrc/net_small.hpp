@@ -32,25 +32,28 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
     const int ct = blockIdx.x % ntile;
     const int rest = blockIdx.x / ntile;
     constexpr int NCT = (BW * BW + 15) / 16;
-    conv_cells_tile<BW, NCQG, NW, LDSX, false>(in, wt, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red, s_x);
+    conv_cells_tile<BW, NCQG, NW, LDSX>(in, wt, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red, s_x);
 }
 
-// The same tile on split-fp16 MFMAs (conv_cells_tile<..., H16>): 128-plane trunk layers of the one-tap-per-wave form. With
+// The same tile on split-fp16 MFMAs (conv_cells_tile_h): 128-plane trunk layers, `bpw` boards per workgroup in turn. With
 // the activations coming from LDS the fp32 MFMAs of the nine waves (9 x 32 x 32 cycles on one CU's four matrix pipes)
 // were what was left of the launch; three 16-cycle fp16 MFMAs per 32-channel block replace eight 32-cycle fp32 ones.
 template <int BW, int NCQG>
 __global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
-                                                            const uint4* __restrict__ wl, const float4* __restrict__ scale,
-                                                            const float4* __restrict__ shift, const float4* res, float4* out,
-                                                            int CQI, int COUT, int relu_res, int* ovf) {
-    __shared__ float s_red[11 * 64 * 4];
+                                                             const uint4* __restrict__ wl, const float4* __restrict__ scale,
+                                                             const float4* __restrict__ shift, const float4* res, float4* out,
+                                                             int CQI, int COUT, int relu_res, int* ovf, int boards, int bpw) {
+    __shared__ float s_red[2 * 11 * 64 * 4];
     __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
+    // grid: output-channel tile fastest (workgroups go round robin over the 8 XCDs: XCD x only ever reads the weights of
+    // tile x), then the cell tile, then the chunk of `bpw` boards this workgroup walks
     const int ntile = COUT >> 4;
     const int ct = blockIdx.x % ntile;
     const int rest = blockIdx.x / ntile;
     constexpr int NCT = (BW * BW + 15) / 16;
-    conv_cells_tile<BW, NCQG, 12, true, true>(in, nullptr, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, rest / NCT, s_red,
-                                              s_x, wh, wl, ovf);
+    const int b0 = (rest / NCT) * bpw;
+    const int nb = boards - b0 < bpw ? boards - b0 : bpw;
+    conv_cells_tile_h<BW, NCQG, 12>(in, wh, wl, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, b0, nb, s_red, s_x, ovf);
 }
 
 

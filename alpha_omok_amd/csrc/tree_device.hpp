@@ -318,7 +318,7 @@ struct MtDev {
 // who made move j as they stood after move j. Written into the evaluation batch.
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
-__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s, int row = -1) {
+__device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const PosR& s, int row = -1, uint8_t* lds_bits = nullptr) {
     const int lane = lane_id();
     // batch row of the native network (active games packed); select_game requests it with the game header -- read here it was a
     // dependent memory round trip at the very end of the kernel (AO_PROF: 1.7 k of the 5 k cycles after the descent)
@@ -330,42 +330,39 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
     // byte array would live in scratch memory)
     const uint64_t last64 = s.last64;
     // Plane q < C-1 is X_{k-j}, j = C-2-q: the stones of the player who made move k-j as they stood after it = that
-    // player's stones now minus his later moves k-j+2, k-j+4, ... (history entries j-2, j-4, ...). Built as a BITBOARD with
-    // wave-uniform operations (a colour's four words, a few bits cleared), so a cell only tests one bit per plane; computed per
-    // cell from the history this function was 4 k of the tree step's 20 k cycles for a single game (AO_PROF).
+    // player's stones now minus his later moves. Per cell that is: "holds a stone of that colour, and the stone is not one of
+    // the last j moves" -- the cell's colour bits and its AGE (index of the cell in the move history, 255 if it is not
+    // among the last eight moves) are found once, every plane is then two compares. (Built plane by plane as bitboards with
+    // the later moves cleared this was ~1000 vector instructions: 4.7 k of the 23 k cycles of a single game's tree step,
+    // AO_PROF; one wave alone issues an instruction every 4-5 cycles.)
     unsigned bits[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) bits[c] = 0u;
+    for (int c = 0; c < NCH; ++c) {
+        const int cell = lane + 64 * c;
+        const unsigned b0 = static_cast<unsigned>((s.bb[0][c] >> lane) & 1ull), b1 = static_cast<unsigned>((s.bb[1][c] >> lane) & 1ull);
+        int age = 255;
 #pragma unroll
-    for (int q = 0; q < kMaxPlanes - 1; ++q) {
-        const int j = C - 2 - q;
-        if (q >= C - 1 || k - j < 1) continue;   // (uniform)
-        const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
-        uint64_t w0 = col ? s.bb[1][0] : s.bb[0][0], w1 = col ? s.bb[1][1] : s.bb[0][1];
-        uint64_t w2 = col ? s.bb[1][2] : s.bb[0][2], w3 = col ? s.bb[1][3] : s.bb[0][3];
+        for (int i = kLastMoves - 1; i >= 0; --i)
+            if (static_cast<int>((last64 >> (8 * i)) & 0xFF) == cell) age = i;
+        unsigned bc = 0u;
 #pragma unroll
-        for (int i = 0; i < kLastMoves; ++i) {
-            if (i >= j || ((j - i) & 1)) continue;   // same parity as j, below j
-            const int mv = static_cast<int>((last64 >> (8 * i)) & 0xFF);
-            if (mv == 0xFF) continue;
-            const uint64_t bit = 1ull << (mv & 63);
-            const int wi = mv >> 6;
-            w0 &= ~(wi == 0 ? bit : 0ull); w1 &= ~(wi == 1 ? bit : 0ull);
-            w2 &= ~(wi == 2 ? bit : 0ull); w3 &= ~(wi == 3 ? bit : 0ull);
+        for (int q = 0; q < kMaxPlanes - 1; ++q) {
+            const int j = C - 2 - q;
+            if (q >= C - 1 || k - j < 1) continue;   // (uniform)
+            const int col = (j & 1) ? stm : (stm ^ 1);   // mover of move k-j: the opponent of the side to move when j is even
+            bc |= ((col ? b1 : b0) & static_cast<unsigned>(age >= j)) << q;
         }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int cell = lane + 64 * c;          // word c of the bitboard, bit `lane` (kBBWords == 4 >= NCH)
-            const uint64_t w = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;
-            bits[c] |= static_cast<unsigned>((w >> lane) & 1ull) << q;
-            (void)cell;
-        }
+        bits[c] = bc;
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int cell = lane + 64 * c;
         if (cell >= p.A) continue;
         const unsigned bq = bits[c] | ((stm == 0) ? (1u << (C - 1)) : 0u);   // + the colour plane
+        if (lds_bits) {   // the fused per-game step (k_step_board): the planes stay in the workgroup, as bits
+            lds_bits[cell] = static_cast<uint8_t>(bq & ((1u << C) - 1u));
+            continue;
+        }
         auto plane = [&](int q) -> float { return (q < C && ((bq >> q) & 1u)) ? 1.f : 0.f; };
         if (p.batch_u8) p.batch_u8[static_cast<size_t>(row) * p.u8_row + cell] = static_cast<uint8_t>(bq & ((1u << C) - 1u));
         if (p.batch_nchw) {
@@ -388,7 +385,7 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
 // k_select
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
-__device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/) {
+__device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr) {
     const int lane = lane_id();
     AO_TT(3);
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
@@ -523,7 +520,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         lp.nchild = 0;
         if (lane == 0) pos_store(p.leaf_pos + g, lp);
         AO_TT(9);
-        encode_planes<NCH>(p, g, lp, batch_row);
+        encode_planes<NCH>(p, g, lp, batch_row, lds_bits);
     }
     AO_TT(10);
     if (lane == 0) {

@@ -74,18 +74,30 @@ STRICT = False               # configure(strict=True): an arena trim raises Tree
 NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 4*(sims+1); -1: grow into the free HBM)
 last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of every search of the last _play_episodes call
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
+CARRY_OVER = False           # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
+CARRY_CALLS = 2              # ... of at most this many calls ahead
+_pool = None                 # games in flight between self_play calls (carry-over mode only)
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
-              model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False):
+              model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
+              carry_over=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
     node_cap: expanded-node capacity of a game's tree arena (0 = 4*(n_mcts+1), -1 = grow into the free HBM);
     strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
     logged and `trim_stats` / self_play's return value carry the counters). reproducible=True evaluates every batch
     size with ONE kernel family (ao_net_set_mode 6): an episode's samples then depend on its seed only, not on how many
-    other episodes share the engine or on MAX_CONCURRENT (slower for very small and very large batches)."""
+    other episodes share the engine or on MAX_CONCURRENT (slower for very small and very large batches).
+    carry_over=True keeps the engine full across self_play calls: a slot whose game ends when no episode of the current
+    call is left to start begins an episode of the NEXT call (same n_selfplay assumed, at most CARRY_CALLS calls ahead) instead
+    of idling while the call's longest games run down; every call still returns exactly its own episodes' samples, in
+    episode order. The price is the reference's strict alternation (main.py:250-262: all of an iteration's games are played
+    by that iteration's network): an episode may have been started -- and partly played -- with the weights of an earlier
+    iteration. Off by default."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
-    global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP
+    global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP, CARRY_OVER, _pool
+    CARRY_OVER = CARRY_OVER if carry_over is None else bool(carry_over)
+    _pool = None
     STRICT = STRICT if strict is None else bool(strict)
     NODE_CAP = NODE_CAP if node_cap is None else int(node_cap)
     _trim_base[0] = _trim_base[1] = 0
@@ -137,8 +149,10 @@ def _get_engine(games):
 
 
 def release_engine():
-    """Free the self-play engine's HBM (trees of MAX_CONCURRENT games); the next self_play() rebuilds it."""
-    global _engine
+    """Free the self-play engine's HBM (trees of MAX_CONCURRENT games); the next self_play() rebuilds it.
+    (Carry-over mode: the games in flight are dropped; their episodes are played again from the start.)"""
+    global _engine, _pool
+    _pool = None
     if _engine is not None:
         _engine.close()
         _engine = None
@@ -167,6 +181,8 @@ def _play_episodes(episodes, use_global, seed_of):
     Returns (moves [E, A] int32 (-1 padded), lengths [E], wins [E], pis: list of [length_e, A] float64 per episode),
     E = len(episodes), rows in the order of `episodes`. Per ply the host only touches whole [G]-arrays; the games
     that finished in that ply are the only per-game work."""
+    global _pool
+    _pool = None                                          # (the engine is reset below: nothing stays in flight)
     E = len(episodes)
     A = BOARD_SIZE * BOARD_SIZE
     G = min(E, MAX_CONCURRENT)
@@ -234,6 +250,119 @@ def _play_episodes(episodes, use_global, seed_of):
     return moves, lengths, wins, rows[order], plies[order], pis[order]
 
 
+class _CarryPool:
+    """Carry-over self-play (configure(carry_over=True)): the engine and its games outlive a self_play call.
+    Episodes are known by their GLOBAL number (episodes played before the call + index in the call), which also fixes
+    their seed, so an episode is the same game whichever call started it (as long as the network did not change under it)."""
+
+    def __init__(self, eng, n_call, rank, world):
+        A = eng.A
+        self.eng, self.n_call, self.rank, self.world = eng, n_call, rank, world
+        self.G = eng.G
+        self.slot_id = np.full(self.G, -1, np.int64)
+        self.ply = np.zeros(self.G, np.int64)
+        self.active = np.zeros(self.G, np.uint8)
+        self.slot_moves = np.full((self.G, A), -1, np.int32)
+        self.finished = {}                                # global id -> (moves [A], length, win)
+        self.hist = []                                    # (ids [n], plies [n], pi [n, A]) per search
+        self.expect = None                                # first global id of the call expected next
+        self.next_call = None                             # first global id of the call the next episode is taken from
+        self.next_pos = 0                                 # ... and the position in this rank's shard of that call
+        self.shard = parallel.shard_games(n_call, rank, world)
+
+    def take_next(self, limit):
+        """Global id of the next episode of this rank to start, or -1 (ids >= limit are not started yet)."""
+        if self.next_pos >= len(self.shard):
+            self.next_call += self.n_call
+            self.next_pos = 0
+        gid = self.next_call + self.shard[self.next_pos]
+        if gid >= limit:
+            return -1
+        self.next_pos += 1
+        return gid
+
+
+def _play_carry(first_episode, n_call, rank, world):
+    """_play_episodes for carry-over mode: returns this rank's episodes of the call [first_episode, first_episode + n_call)
+    -- some of them started, or even finished, during earlier calls -- and leaves later calls' games in flight."""
+    global _pool
+    A = BOARD_SIZE * BOARD_SIZE
+    shard = parallel.shard_games(n_call, rank, world)
+    G = min(len(shard), MAX_CONCURRENT)
+    eng = _get_engine(G)
+    pool = _pool
+    if pool is None or pool.eng is not eng or (pool.n_call, pool.rank, pool.world, pool.expect) != (n_call, rank, world, first_episode):
+        if pool is not None:
+            logging.warning('carry-over self-play: n_selfplay / world size / episode numbering changed, %d games in flight dropped',
+                            int(pool.active.sum()))
+        pool = _pool = _CarryPool(eng, n_call, rank, world)
+        pool.next_call = first_episode
+        eng.reset()
+    pool.expect = first_episode + n_call                 # the call that may pick these games up
+    limit = first_episode + n_call * (1 + CARRY_CALLS)
+    seed_of = lambda gid: (SEED + gid) & 0xFFFFFFFF
+    mine = np.asarray([first_episode + e for e in shard], np.int64)
+    todo = set(int(i) for i in mine) - set(pool.finished)
+
+    def start(slots):
+        mask = np.zeros(G, np.uint8)
+        for g in slots:
+            gid = pool.take_next(limit)
+            if gid < 0:
+                break
+            mask[g] = 1
+            pool.slot_id[g] = gid
+        if mask.any():
+            eng.reset(mask)                               # Agent.reset() (main.py:248)
+            for g in np.flatnonzero(mask):
+                eng.seed(int(g), seed_of(int(pool.slot_id[g])))
+            pool.active[mask != 0] = 1
+            pool.ply[mask != 0] = 0
+            pool.slot_moves[mask != 0] = -1
+
+    start(np.flatnonzero(pool.active == 0))
+    trace = [] if os.environ.get("AO_SELFPLAY_TRACE") else None
+    while todo:
+        if not pool.active.any():
+            raise RuntimeError("carry-over self-play: episodes %r are neither in flight nor finished" % sorted(todo)[:8])
+        tau = (pool.ply < TAU_THRES).astype(np.int8)      # main.py:150-153
+        t_search = time.perf_counter()
+        pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=pool.active)
+        act, win = eng.play()
+        if trace is not None:
+            trace.append((int(pool.active.sum()), time.perf_counter() - t_search))
+        on = np.flatnonzero(pool.active)
+        pool.hist.append((pool.slot_id[on].copy(), pool.ply[on].copy(), pi[on]))
+        pool.slot_moves[on, pool.ply[on]] = act[on]
+        pool.ply[on] += 1
+        done = on[win[on] != 0]
+        if done.size:
+            for g in done:                                # finished games only
+                gid = int(pool.slot_id[g])
+                pool.finished[gid] = (pool.slot_moves[g].copy(), int(pool.ply[g]), int(win[g]))
+                todo.discard(gid)
+                pool.slot_id[g] = -1
+            pool.active[done] = 0
+            start(done)
+    _check_trim(eng)
+    if trace is not None:
+        last_trace[:] = trace
+    # this call's episodes out of the pool; the rest stays for the calls to come
+    ids = np.concatenate([h[0] for h in pool.hist])
+    plies = np.concatenate([h[1] for h in pool.hist])
+    pis = np.concatenate([h[2] for h in pool.hist])
+    sel = (ids >= first_episode) & (ids < first_episode + n_call)
+    pool.hist = [(ids[~sel], plies[~sel], pis[~sel])] if (~sel).any() else []
+    ids, plies, pis = ids[sel], plies[sel], pis[sel]
+    rows = np.searchsorted(mine, ids)
+    order = np.lexsort((plies, rows))
+    recs = [pool.finished.pop(int(i)) for i in mine]
+    moves = np.stack([r[0] for r in recs])
+    lengths = np.asarray([r[1] for r in recs], np.int64)
+    wins = np.asarray([r[2] for r in recs], np.int64)
+    return moves, lengths, wins, rows[order], plies[order], pis[order]
+
+
 def self_play(n_selfplay, seeds=None, single_stream=False):
     """Plays n_selfplay episodes and appends their samples to cur_memory / rep_memory exactly as the
     reference does: per episode, plies in chronological order, (state [C,B,B] f64, pi [A] f64, z).
@@ -272,6 +401,11 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         ep_of = np.concatenate([np.full(p[3].shape[0], i, np.int64) for i, p in enumerate(parts)])
         ply_of = np.concatenate([p[4] for p in parts])
         pis = np.concatenate([p[5] for p in parts])
+    elif CARRY_OVER:
+        if seeds is not None:
+            raise ValueError("carry-over self-play starts episodes of later calls: their seeds are SEED + episode number, "
+                             "an explicit seeds= list cannot be honoured")
+        moves, lengths, wins, ep_of, ply_of, pis = _play_carry(first_episode, n_selfplay, rank, world)
     else:
         moves, lengths, wins, ep_of, ply_of, pis = _play_episodes(episodes, False, seed_of)
 

@@ -182,6 +182,56 @@ def test_reproducible_mode_makes_an_episode_independent_of_its_neighbours():
     main.release_engine()
 
 
+def test_carry_over_self_play_returns_each_calls_own_episodes():
+    """configure(carry_over=True): slots freed near the end of a call start the NEXT calls' episodes, the engine never runs
+    down to one game. With an unchanged network and one kernel family (reproducible=True) every episode must still be the game
+    its seed fixes: three calls of 7 episodes on 4 slots give call by call the same cur_memory / results / replay as the
+    synchronous schedule, and games of later calls are in flight when a call returns."""
+    import torch
+    import alpha_omok_amd.main as main
+    B, S, N = 9, 16, 7
+
+    def run(carry):
+        torch.manual_seed(5)
+        main.MAX_CONCURRENT = 4
+        main.configure(board_size=B, n_mcts=S, n_blocks=2, in_planes=5, out_planes=128, seed=40, reproducible=True, node_cap=0,
+                       strict=True, carry_over=carry)
+        main.result.update(Black=0, White=0, Draw=0)
+        main.rep_memory.clear()
+        out = []
+        in_flight = []
+        for _ in range(3):
+            main.cur_memory.clear()
+            ret = main.self_play(N)
+            assert ret['episodes'] == N and ret['moves'] == len(main.cur_memory)
+            out.append([(s.copy(), p.copy(), z) for s, p, z in main.cur_memory])
+            in_flight.append(int(main._pool.active.sum()) if main._pool is not None else 0)
+        res = dict(main.result)
+        rep = [(s.copy(), p.copy(), z) for s, p, z in list(main.rep_memory)]
+        main.MAX_CONCURRENT = 4096
+        return out, res, rep, in_flight
+
+    sync, res0, rep0, fl0 = run(False)
+    carry, res1, rep1, fl1 = run(True)
+    assert fl0 == [0, 0, 0] and all(f > 0 for f in fl1), (fl0, fl1)
+    assert res0 == res1
+    for c in range(3):
+        assert len(sync[c]) == len(carry[c])
+        for (s0, p0, z0), (s1, p1, z1) in zip(sync[c], carry[c]):
+            assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+    assert len(rep0) == len(rep1)
+    for (s0, p0, z0), (s1, p1, z1) in zip(rep0, rep1):
+        assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+    # a call with another n_selfplay cannot use the games in flight: they are dropped, the call is still complete
+    main.cur_memory.clear()
+    ret = main.self_play(3)
+    assert ret['episodes'] == 3 and sum(1 for s, _, _ in main.cur_memory if not s[:4].any()) == 3
+    with pytest.raises(ValueError):
+        main.self_play(3, seeds=[1, 2, 3])
+    main.configure(board_size=B, n_mcts=S, n_blocks=2, out_planes=128, seed=0, reproducible=False, strict=False, carry_over=False)
+    main.release_engine()
+
+
 def test_self_play_reports_arena_trims_and_strict_mode_raises(oracle):
     """A tree arena too small for what the searches keep from move to move makes re-rooting forget subtrees -- a
     divergence from the reference's never-pruned dict (agents.py:52) that must not pass silently: self_play returns /

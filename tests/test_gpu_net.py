@@ -438,3 +438,44 @@ def test_fused_search_packs_active_games_only(mode, planes):
     e1.close()
     e2.close()
     net.close()
+
+
+@pytest.mark.parametrize("B,G,S,nb,C", [(9, 1, 64, 2, 5), (9, 5, 48, 2, 5), (15, 3, 24, 1, 5), (9, 40, 16, 1, 7), (5, 7, 20, 1, 3)])
+def test_fused_per_game_step_equals_separate_launches(B, G, S, nb, C, monkeypatch):
+    """A few games on a 128-plane network: ao_search runs heads + expansion / backup / selection + the next leaf's conv1 as ONE
+    launch per game (k_step_board, step_kernels.hip). The tree code is the same device code; conv1 is formulated differently
+    (K = tap * 8 + plane on fp16 MFMAs with split weights instead of fp32 MFMAs per tap), exact products of 0/1 planes with
+    fp32 accumulation either way. The searches must agree with the three-launch form (AO_FUSED_STEP=0): same visits, priors,
+    moves and stream positions over several plies, with a changing active mask."""
+    from alpha_omok_amd.engine import Engine
+    net = _native(nb, C, 128, B, 31)
+    seeds = np.arange(70, 70 + G, dtype=np.uint32)
+    e1 = Engine(B, S, C, games=G, noise=True)
+    e2 = Engine(B, S, C, games=G, noise=True)
+    e1.seed_all(seeds)
+    e2.seed_all(seeds)
+    rs = np.random.RandomState(1)
+    for t in range(4):
+        tau = np.full(G, 1 if t < 2 else 0, np.int8)
+        active = np.ones(G, np.uint8)
+        if t == 2 and G > 2:
+            active = (rs.rand(G) < 0.6).astype(np.uint8)
+            active[0] = 1
+        monkeypatch.delenv("AO_FUSED_STEP", raising=False)
+        pi1, vis1, pol1 = e1.search(net, tau=tau, active=active)
+        monkeypatch.setenv("AO_FUSED_STEP", "0")
+        pi2, vis2, pol2 = e2.search(net, tau=tau, active=active)
+        on = active.astype(bool)
+        np.testing.assert_array_equal(vis1[on], vis2[on])
+        np.testing.assert_allclose(pol1[on], pol2[on], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(pi1[on], pi2[on])
+        a1, w1 = e1.play()
+        a2, w2 = e2.play()
+        np.testing.assert_array_equal(a1, a2)
+        np.testing.assert_array_equal(w1, w2)
+        for g in range(G):
+            assert e1.get_rng_state(g)[1] == e2.get_rng_state(g)[1]
+    assert net.status() == 0
+    e1.close()
+    e2.close()
+    net.close()

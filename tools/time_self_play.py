@@ -1,5 +1,7 @@
 """End-to-end main.self_play(n) timing (host bookkeeping, sample emission and augmentation included):
-    python tools/time_self_play.py [games] [sims] [blocks] [device_replay 0/1]"""
+    python tools/time_self_play.py [games] [sims] [blocks] [device_replay 0/1] [carry_over calls]
+With carry_over calls > 0: configure(carry_over=True) and that many consecutive self_play(games) calls after two untimed calls
+(the steady state of the training loop: every call returns its own episodes, later calls' games keep the slots busy)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +10,24 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sims = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dr = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
-main.configure(board_size=9, n_mcts=sims, n_blocks=nb, seed=0, device_replay=dr)
+carry = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+main.configure(board_size=9, n_mcts=sims, n_blocks=nb, seed=0, device_replay=dr, carry_over=carry > 0)
+if carry:
+    main.self_play(n)                 # untimed: fills the pipeline (the first call starts all its games at once,
+    main.self_play(n)                 # the second still sees that wave of simultaneous game ends)
+    main.cur_memory.clear(); main.rep_memory.clear()
+    t0 = time.perf_counter()
+    per = []
+    for _ in range(carry):
+        t1 = time.perf_counter()
+        r = main.self_play(n)
+        per.append((r['moves'], time.perf_counter() - t1))
+    dt = time.perf_counter() - t0
+    moves = len(main.cur_memory)
+    print("carry-over: %d x self_play(%d) @%d sims, %d blocks, device_replay=%s: %.1f s, %d move decisions returned = %.0f move-decisions/s "
+          "(per call: %s); %d games of later calls in flight" % (carry, n, sims, nb, dr, dt, moves, moves / dt,
+          ", ".join("%.0f" % (m / t) for m, t in per), int(main._pool.active.sum())))
+    sys.exit(0)
 main.self_play(min(n, 64))            # warm-up: builds the engine, exports the net
 main.cur_memory.clear(); main.rep_memory.clear()
 os.environ["AO_SELFPLAY_TRACE"] = "1"
