@@ -70,6 +70,60 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_run(tmp_path):
     assert seen == set(range(EPISODES))
 
 
+def _run_calls(calls, carry, conc):
+    """`calls` consecutive self_play(EPISODES) calls; one sample list per call."""
+    from alpha_omok_amd import main
+    main.MAX_CONCURRENT = conc
+    main.configure(board_size=B, n_mcts=S, n_blocks=NB, in_planes=5, out_planes=128, seed=11, gpu=0, node_cap=0, strict=False,
+                   carry_over=carry)
+    out = []
+    for _ in range(calls):
+        main.cur_memory.clear()
+        main.self_play(EPISODES)
+        out.append([(np.asarray(s, np.float64), np.asarray(p, np.float64), float(z)) for s, p, z in main.cur_memory])
+    in_flight = int(main._pool.active.sum()) if main._pool is not None else 0
+    main.MAX_CONCURRENT = 4096
+    main.configure(board_size=B, n_mcts=S, n_blocks=NB, in_planes=5, out_planes=128, seed=7, gpu=0, carry_over=False)
+    return out, in_flight
+
+
+def _carry_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from alpha_omok_amd import parallel
+    parallel.init_from_env("gloo")
+    mems, in_flight = _run_calls(3, True, 2)
+    torch.save(dict(mems=mems, in_flight=in_flight), out % rank)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_carry_over_return_their_shards_of_every_call(tmp_path):
+    """configure(carry_over=True) under two ranks: each rank keeps ITS shard's episodes of the later calls in flight (two
+    slots per rank, three episodes per rank and call) and returns, call by call, exactly the episodes e % 2 == rank of that
+    call -- the same samples a single process produces for them with the synchronous schedule."""
+    single, fl = _run_calls(3, False, 4096)
+    assert fl == 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "carry%d.pt")
+    mp.spawn(_carry_worker, args=(2, port, out), nprocs=2, join=True)
+    for rank in range(2):
+        r = torch.load(out % rank, weights_only=False)
+        assert r["in_flight"] > 0
+        for c in range(3):
+            want = _episodes_of(single[c])
+            got = _episodes_of(r["mems"][c])
+            shard = list(range(rank, EPISODES, 2))
+            assert len(want) == EPISODES and len(got) == len(shard)
+            for e, g in zip(shard, got):
+                assert len(g) == len(want[e]), "call %d episode %d: %d plies on rank %d, %d alone" % (c, e, len(g), rank, len(want[e]))
+                for (s0, p0, z0), (s1, p1, z1) in zip(g, want[e]):
+                    assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+
+
 def _run_worker(rank, world, port, out, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
