@@ -1,9 +1,11 @@
 // step_kernels.hip -- the fused per-game search step of the small-batch ("latency") path.
 //
 // A handful of concurrent games (BASELINE configs[1]: ONE game, 400 simulations per move) makes every kernel of a simulation a
-// few microseconds long, and what a simulation costs is then the NUMBER of launches: every launch boundary is a drain, a
-// dispatch and a cold start (kernel arguments, instruction cache, the first dependent loads). k_step_board does what three
-// launches did -- k_heads_board, k_expand_select and conv1's k_conv_cells -- in one workgroup per game:
+// few microseconds long. k_step_board does what three launches did -- k_heads_board, k_expand_select and conv1's
+// k_conv_cells -- in one workgroup per game. Measured (end): for ONE game it is a wash (54.7 vs 54.4 us per
+// simulation: the launches already followed each other without idle time and the three phases cost inside one kernel what
+// they cost alone); from a few games on it wins, because a game's step is one 16-wave workgroup instead of three tiny grids
+// (8 / 24 / 48 games: +1 / +2.7 / +4 %). AO_FUSED_STEP=0 falls back to the three launches.
 //
 //   all 16 waves   policy + value head of the game's last leaf from the trunk's output   (heads_board_dev; model.py:34-73)
 //   wave 0         expansion + backup of that leaf, selection of the next one, its input planes as bits in LDS
