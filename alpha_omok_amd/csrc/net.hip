@@ -185,7 +185,9 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     if (mode == 6) mode = 5;   // mode 6 = mode 5 restricted to the per-layer kernels (layers_only()): one arithmetic for every batch size
     if (mode == 0) {
         const long cells = static_cast<long>(boards) * n->A;
-        if (h16_supported(n)) mode = cells <= 4900 ? 3 : 5;   // (round 3: 60 9x9 boards -- 582 vs 513 move-decisions/s at 48 games, 637 vs 665 at 64, with the LDS + split-fp16 tile kernel)
+        // (end of round 3, with the activations split once at staging and the fused per-game step: 9x9 per-board vs per-layer
+        // 841 vs 653 move-decisions/s at 64 games, 983 vs 960 at 96, 1076 vs 1281 at 128; 15x15 equal at 24 games, 581 vs 816 at 36)
+        if (h16_supported(n)) mode = cells <= (n->B <= 9 ? 7776 : 5400) ? 3 : 5;
         else mode = cells <= 13000 ? 3 : (g16 >= 192 ? 2 : 4);
     }
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;

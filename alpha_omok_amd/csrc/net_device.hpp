@@ -233,9 +233,10 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
         const int u = NUH * w3 + j, tap = u / NC32, c = u - tap * NC32;
         const int yy = cy + tap / 3 - 1, xx = cx + tap % 3 - 1;
         xok[j] = cell < A && yy >= 0 && yy < BW && xx >= 0 && xx < BW;
-        xoff[j] = (xok[j] ? (yy - r0) * BW + xx : 0) * QS + kq * 2 + c * 8;
+        xoff[j] = (xok[j] ? (yy - r0) * BW + xx : 0) * QS + c * 8 + kq * 2;
     }
-    const int nq = (r1 - r0 + 1) * BW * (NCQG * 4);
+    const int nq = (r1 - r0 + 1) * BW * (NCQG * 2);   // staging items: (cell, 8-channel group)
+    uint4* s_xh = reinterpret_cast<uint4*>(s_x);
     float peak = 0.f;
     for (int bi = 0; bi < nb; ++bi) {
         const int board = board0 + bi;
@@ -243,30 +244,37 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
         float4 e_res = make_float4(0.f, 0.f, 0.f, 0.f);
         if (w3 == 0 && relu_res && cell < A) e_res = res[o_idx];
         // the tile's board rows of this board into LDS (every wave has finished reading the previous board's: they all
-        // passed the reduction barrier below after their LDS reads)
+        // passed the reduction barrier below after their LDS reads) -- split into fp16 high / low halves HERE, once per
+        // element: 8 consecutive channels per thread, stored as the 16-byte operand groups the MFMAs read. (Split by the
+        // consuming waves, every element was converted up to nine times -- once per tap -- and the ~150 vector instructions
+        // per lane sat between the operands' arrival and the first MFMA.)
         {
             const float4* src = in + (static_cast<size_t>(board) * A + static_cast<size_t>(r0) * BW) * CQI;
             for (int i = threadIdx.x; i < nq; i += NW * 64) {
-                const int c = i / (NCQG * 4), q = i - c * (NCQG * 4);
-                s_x[c * QS + q] = src[i];
+                const int c = i / (NCQG * 2), o = i - c * (NCQG * 2);   // cell of the staged rows, group of 8 channels
+                const float4 q0 = src[c * (NCQG * 4) + 2 * o], q1 = src[c * (NCQG * 4) + 2 * o + 1];
+                const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                cc_half8 xh, xl;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    peak = fmaxf(peak, v[k]);
+                    const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
+                    const _Float16 hh = static_cast<_Float16>(t);
+                    xh[k] = hh;
+                    xl[k] = static_cast<_Float16>(t - static_cast<float>(hh));
+                }
+                uint4* dst = s_xh + c * QS + o * 2;   // [cell][32-channel block][8-channel group][high | low]
+                dst[0] = __builtin_bit_cast(uint4, xh);
+                dst[1] = __builtin_bit_cast(uint4, xl);
             }
         }
         __syncthreads();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 #pragma unroll
         for (int j = 0; j < NUH; ++j) {
-            float4 q0 = s_x[xoff[j]], q1 = s_x[xoff[j] + 1];
-            if (!xok[j]) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
-            const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            cc_half8 xh, xl;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                peak = fmaxf(peak, v[k]);
-                const float t = fminf(v[k], 65504.f);   // (inputs are post-ReLU; beyond the fp16 range: clamped and reported)
-                const _Float16 hh = static_cast<_Float16>(t);
-                xh[k] = hh;
-                xl[k] = static_cast<_Float16>(t - static_cast<float>(hh));
-            }
+            uint4 uh = s_xh[xoff[j]], ul = s_xh[xoff[j] + 1];
+            if (!xok[j]) { uh = make_uint4(0u, 0u, 0u, 0u); ul = uh; }
+            const cc_half8 xh = __builtin_bit_cast(cc_half8, uh), xl = __builtin_bit_cast(cc_half8, ul);
             // one accumulator chain per unit (up to four); hh, hl, lh of a unit go to the same chain
             f32x4& a = (j & 3) == 0 ? acc0 : (j & 3) == 1 ? acc1 : (j & 3) == 2 ? acc2 : acc3;
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xh, a, 0, 0, 0);

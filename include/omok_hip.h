@@ -173,7 +173,7 @@ int  ao_net_forward(ao_net *n, const float *dev_planes_nchw, int batch, float *d
  * path's; activations are clamped to the fp16 range, 65504). Mode 5 needs 128 planes and at least one
  * ResBlock; it runs as one resident launch (boards up to 9x9, >= 3072 boards) or as one launch per conv
  * over (16-board group x row chunk x column tile) (any board up to 15x15, smaller batches), and is
- * what mode 0 picks on such a net for batches of more than ~4900 cells (60 9x9 boards). 6 = mode 5 restricted to
+ * what mode 0 picks on such a net for batches of more than ~7800 cells (96 9x9 boards; 5400 cells on wider boards). 6 = mode 5 restricted to
  * the per-layer kernels for EVERY batch size: slower at both ends, but the arithmetic that evaluates a position is then
  * the same whatever else shares the batch, so a game's trajectory under ao_search depends on its own stream and moves
  * only (modes 0 / 5 switch kernel families with the number of active games; all within 1e-4 of model.py:76-104). */
