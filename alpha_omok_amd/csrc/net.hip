@@ -411,7 +411,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             hipMemcpyFromSymbol(h, HIP_SYMBOL(ao_prof_heads), sizeof(h));
             unsigned long long cv[8];
             hipMemcpyFromSymbol(cv, HIP_SYMBOL(ao_prof_conv), sizeof(cv));
-            fprintf(stderr, "AO_PROF k_conv_cells (last layer, block 0, wave 0) ticks: operands %llu, MFMAs %llu, barrier %llu, reduce+epilogue+store %llu, total %llu\n",
+            fprintf(stderr, "AO_PROF k_conv_cells_h (last layer, block 0, wave 0) ticks: rows loaded + split + stored %llu, barrier + LDS reads + MFMAs %llu, reduction barrier %llu, reduce+epilogue+store %llu, total %llu\n",
                     cv[1] - cv[0], cv[2] - cv[1], cv[3] - cv[2], cv[4] - cv[3], cv[4] - cv[0]);
             fprintf(stderr, "AO_PROF k_heads_board ticks: w3 %llu, 1x1 conv %llu, reduce %llu, FC %llu, softmax+value %llu, tanh/store %llu, total %llu\n",
                     h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);

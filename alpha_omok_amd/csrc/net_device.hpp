@@ -268,6 +268,7 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
                 dst[1] = __builtin_bit_cast(uint4, xl);
             }
         }
+        AO_CT(1);
         __syncthreads();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 #pragma unroll
@@ -284,12 +285,14 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
         f32x4 acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+        AO_CT(2);
         float* red = s_red + (bi & 1) * (NW - 1) * 64 * 4;
         if (w3 > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((w3 - 1) * 64 + lane) * 4 + r] = acc[r];
         }
         __syncthreads();
+        AO_CT(3);
         if (w3 == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

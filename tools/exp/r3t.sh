@@ -1,3 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for g in 16 24 36 48; do for m in 3 6; do echo -n "15x15 games $g mode $m  "; python tools/time_single_game.py --moves 3 --board 15 --games $g --mode $m --sims 200 2>&1 | grep "us/sim"; done; done
-for g in 80 100 112; do for m in 3 6; do echo -n "9x9 games $g mode $m  "; python tools/time_single_game.py --moves 4 --games $g --mode $m 2>&1 | grep "us/sim"; done; done
+for i in 1 2; do
+echo -n "1 game  "; python tools/time_single_game.py --moves 12 2>&1 | grep "us/sim"
+done
+for g in 8 24 48; do echo -n "games $g  "; python tools/time_single_game.py --moves 6 --games $g 2>&1 | grep "us/sim"; done
+AO_LIB_TAG=prof AO_PROF_PRINT=1 AO_FUSED_STEP=0 python tools/time_single_game.py --moves 1 2>&1 | grep "AO_PROF k_conv" | tail -2
+python -m pytest tests/test_gpu_net.py -x -q 2>&1 | tail -3
