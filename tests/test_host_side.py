@@ -322,3 +322,27 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     assert len(main.rep_memory) == 3 and main.rep_memory.maxlen == main.MEMORY_SIZE
     for k, v in sd.items():
         assert torch.equal(fresh.state_dict()[k], v)
+
+
+def test_carry_over_pool_numbers_episodes_across_calls_and_ranks():
+    """main._CarryPool.take_next (carry-over self-play): a rank starts ITS episodes of the current call, then of the next calls,
+    in global episode order, and stops at the look-ahead limit -- host logic only, no device."""
+    from types import SimpleNamespace
+    from alpha_omok_amd import main
+    eng = SimpleNamespace(A=81, G=4)
+    for rank, world, n_call, first in ((0, 1, 5, 0), (1, 2, 7, 14), (2, 3, 4, 8)):
+        pool = main._CarryPool(eng, n_call, rank, world)
+        pool.next_call = first
+        limit = first + 3 * n_call
+        got = []
+        while True:
+            gid = pool.take_next(limit)
+            if gid < 0:
+                break
+            got.append(gid)
+        want = [first + c * n_call + e for c in range(3) for e in range(rank, n_call, world)]
+        assert got == want, (rank, world, n_call, got, want)
+        assert pool.take_next(limit) == -1                      # stays stopped at the limit ...
+        more = pool.take_next(limit + n_call)                   # ... and goes on when the limit moves (the next call)
+        nxt = [first + 3 * n_call + e for e in range(rank, n_call, world)]
+        assert more == (nxt[0] if nxt else -1)
