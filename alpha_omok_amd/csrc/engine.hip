@@ -172,10 +172,22 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     if (c.device < 0 || c.device >= ndev) return e->fail("device ordinal out of range");
     AO_HIP(e, hipSetDevice(c.device));
     if (c.node_cap == 0) {
-        // Default arena: 4 x (sims + 1) expanded nodes per game -- what a random-init network's searches need, and a
-        // DETERMINISTIC number: whether re-rooting has to forget subtrees (ao_trim_stats) must not depend on what else
-        // happens to occupy the GPU when the engine is created.
-        c.node_cap = static_cast<int32_t>(std::min<long>(4L * (c.sims + 1), 15000));
+        // Default arena: 16 x (sims + 1) expanded nodes per game where the part is large enough, never less than
+        // 4 x (sims + 1). Re-rooting keeps the chosen child's subtree, so with a share f of the root's visits in that
+        // child the kept tree settles at f / (1 - f) x sims nodes: 4 x holds f <= 0.75 (a random-init network stays far
+        // below), 16 x holds f <= 0.93 -- what a trained, sharp policy needs, and the reference's dict never forgets
+        // (agents.py:52). The number is DETERMINISTIC for a given device model: bounded by 30 % of the device's TOTAL
+        // memory for the two arenas (4096 games x 400 sims on a 288 GB MI355X: 4672 nodes = 11.6 x sims, 95 GB), not by
+        // what happens to be free when the engine is created -- whether re-rooting has to forget subtrees
+        // (ao_trim_stats) must not depend on the GPU's other tenants.
+        const int Ap_ = (c.board * c.board + 15) / 16 * 16;
+        const double node_bytes = Ap_ * 25.0 + 80.0;     // N, W, Q, CH 4 B + P 8 B + ACT 1 B per edge slot, + the position
+        size_t free_b = 0, total_b = 0;
+        long cap = 16L * (c.sims + 1);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            cap = std::min<long>(cap, static_cast<long>(0.30 * static_cast<double>(total_b) / (2.0 * c.games * node_bytes)));
+        cap = std::max<long>(cap, 4L * (c.sims + 1));
+        c.node_cap = static_cast<int32_t>(std::min<long>(cap, 15000));
     } else if (c.node_cap < 0) {
         // node_cap = -1, opt-in: grow into the HBM that is free right now -- up to a quarter of it, at most
         // 16 x (sims + 1) -- for sharp (trained) policies that keep more of the tree from move to move. 4096 games x

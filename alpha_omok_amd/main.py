@@ -54,6 +54,8 @@ BATCH_SIZE = 32
 LR = 2e-4
 L2 = 0
 MAX_CONCURRENT = 4096   # games resident on one GPU at a time
+GAMES_PER_ITER = None   # run(): games of every iteration after the first (None: the reference's ONE game -- per rank)
+TRAIN_STEPS = None      # train(): mini-batches per pass (None: the reference's len(cur_memory), main.py:263-264)
 
 rep_memory = deque(maxlen=MEMORY_SIZE)
 cur_memory = deque()
@@ -71,7 +73,7 @@ _episodes_played = 0
 _trim_seen = [0]
 _trim_base = [0, 0]          # counters of engines that were closed since configure()
 STRICT = False               # configure(strict=True): an arena trim raises TreeTrimmed instead of logging a warning
-NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 4*(sims+1); -1: grow into the free HBM)
+NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 16*(sims+1) within 30 % of the HBM; -1: grow into the free HBM)
 last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of every search of the last _play_episodes call
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 CARRY_OVER = False           # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
@@ -83,7 +85,8 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
               model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
               carry_over=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
-    node_cap: expanded-node capacity of a game's tree arena (0 = 4*(n_mcts+1), -1 = grow into the free HBM);
+    node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 30 % of the HBM
+    holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
     strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
     logged and `trim_stats` / self_play's return value carry the counters). reproducible=True evaluates every batch
     size with ONE kernel family (ao_net_set_mode 6): an episode's samples then depend on its seed only, not on how many
@@ -154,6 +157,10 @@ def release_engine():
     global _engine, _pool
     _pool = None
     if _engine is not None:
+        d, t = _engine.trim_stats()                       # the cumulative counters outlive the engine
+        _trim_base[0] += d
+        _trim_base[1] += t
+        _trim_seen[0] = 0
         _engine.close()
         _engine = None
 
@@ -178,8 +185,9 @@ def _check_trim(eng):
 
 def _play_episodes(episodes, use_global, seed_of):
     """Plays the listed episodes on one engine (G = min(len, MAX_CONCURRENT) slots, finished slots refilled).
-    Returns (moves [E, A] int32 (-1 padded), lengths [E], wins [E], pis: list of [length_e, A] float64 per episode),
-    E = len(episodes), rows in the order of `episodes`. Per ply the host only touches whole [G]-arrays; the games
+    Returns (moves [E, A] int32 (-1 padded), lengths [E], wins [E], ep_of [N], ply_of [N], pis [N, A] float64):
+    E = len(episodes), rows in the order of `episodes`; the N = sum(lengths) samples sorted by (row, ply), sample i
+    being the search at ply ply_of[i] of row ep_of[i]. Per ply the host only touches whole [G]-arrays; the games
     that finished in that ply are the only per-game work."""
     global _pool
     _pool = None                                          # (the engine is reset below: nothing stays in flight)
@@ -374,7 +382,7 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
 
     Returns a summary dict (the reference returns None): episodes and move decisions of this rank, and the
     cumulative arena-trim counters (`trim_stats`; with configure(strict=True) a trim raises TreeTrimmed)."""
-    global _episodes_played
+    global _episodes_played, _pool
     if Agent is None:
         configure()
     if hasattr(Agent.model, "eval"):
@@ -393,21 +401,30 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
 
     A = BOARD_SIZE * BOARD_SIZE
-    if single_stream or (n_selfplay == 1 and seeds is None and world == 1):
-        parts = [_play_episodes([ep], True, seed_of) for ep in episodes]   # sequential, each on the global stream where the last left it
-        moves = np.concatenate([p[0] for p in parts])
-        lengths = np.concatenate([p[1] for p in parts])
-        wins = np.concatenate([p[2] for p in parts])
-        ep_of = np.concatenate([np.full(p[3].shape[0], i, np.int64) for i, p in enumerate(parts)])
-        ply_of = np.concatenate([p[4] for p in parts])
-        pis = np.concatenate([p[5] for p in parts])
-    elif CARRY_OVER:
-        if seeds is not None:
-            raise ValueError("carry-over self-play starts episodes of later calls: their seeds are SEED + episode number, "
-                             "an explicit seeds= list cannot be honoured")
-        moves, lengths, wins, ep_of, ply_of, pis = _play_carry(first_episode, n_selfplay, rank, world)
-    else:
-        moves, lengths, wins, ep_of, ply_of, pis = _play_episodes(episodes, False, seed_of)
+    try:
+        if single_stream or (n_selfplay == 1 and seeds is None and world == 1):
+            parts = [_play_episodes([ep], True, seed_of) for ep in episodes]   # sequential, each on the global stream where the last left it
+            moves = np.concatenate([p[0] for p in parts])
+            lengths = np.concatenate([p[1] for p in parts])
+            wins = np.concatenate([p[2] for p in parts])
+            ep_of = np.concatenate([np.full(p[3].shape[0], i, np.int64) for i, p in enumerate(parts)])
+            ply_of = np.concatenate([p[4] for p in parts])
+            pis = np.concatenate([p[5] for p in parts])
+        elif CARRY_OVER:
+            if seeds is not None:
+                raise ValueError("carry-over self-play starts episodes of later calls: their seeds are SEED + episode number, "
+                                 "an explicit seeds= list cannot be honoured")
+            moves, lengths, wins, ep_of, ply_of, pis = _play_carry(first_episode, n_selfplay, rank, world)
+        else:
+            moves, lengths, wins, ep_of, ply_of, pis = _play_episodes(episodes, False, seed_of)
+    except BaseException:
+        # a call that did not deliver (TreeTrimmed under strict=True, an engine error, Ctrl-C) leaves nothing behind:
+        # the episode numbering is where it was -- a retry plays the same episodes with the same seeds -- and the
+        # carry-over pool is dropped (its finished-but-undelivered episodes and pi histories would otherwise stay in
+        # it forever and the later calls' games would keep occupying slots)
+        _episodes_played = first_episode
+        _pool = None
+        raise
 
     # results and samples in episode order (main.py:201-227); samples arrive sorted by (episode, ply)
     result['Black'] += int((wins == 1).sum())
@@ -416,7 +433,7 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     reward_black = np.where(wins == 1, 1., np.where(wins == 2, -1., 0.))
     z = np.where(ply_of % 2 == 0, reward_black[ep_of], -reward_black[ep_of])
     z = np.where(z == 0, 0., z)                           # (no -0.0: the reference's draw reward is +0.0 for both colours)
-    states = utils.states_of_episodes(moves, lengths, ep_of, ply_of, BOARD_SIZE, IN_PLANES)
+    states = utils.states_of_episodes(moves, ep_of, ply_of, BOARD_SIZE, IN_PLANES)
     n_new = states.shape[0]
     zl = z.tolist()
     cur_memory.extend(zip(states, pis, zl))               # rows of the big arrays: (state f64 [C,B,B], pi f64 [A], z float)
@@ -473,6 +490,10 @@ def train(n_epochs, n_iter):
     behaviour included: random.sample raises ValueError when rep_memory holds fewer than
     32*len(cur_memory) entries (main.py:263-264).
 
+    TRAIN_STEPS (module constant, None by default) replaces the reference's len(cur_memory) mini-batches per pass:
+    with thousands of concurrent games per iteration one mini-batch per NEW sample is hours of optimiser steps;
+    BATCH_SIZE x TRAIN_STEPS then sets the replay draws per pass (tools/train_omok.py).
+
     Under torch.distributed (one process per GPU, rank-local cur_memory / rep_memory) it is the
     data-parallel form of the same pass. The ranks first agree on the number of mini-batches --
     ceil(sum over ranks of len(cur_memory) / world), so every new sample still buys 32 replay draws in
@@ -486,10 +507,10 @@ def train(n_epochs, n_iter):
     Agent.model.train()
     on_device = hasattr(rep_memory, "batch")
     if world == 1:
-        n_steps = len(cur_memory)
+        n_steps = len(cur_memory) if TRAIN_STEPS is None else int(TRAIN_STEPS)
         n = BATCH_SIZE * n_steps
     else:
-        n_steps = -(-parallel.agree(len(cur_memory), "sum", device) // world)
+        n_steps = -(-parallel.agree(len(cur_memory), "sum", device) // world) if TRAIN_STEPS is None else int(TRAIN_STEPS)
         n = min(BATCH_SIZE * n_steps, len(rep_memory))
     # random.sample picks POSITIONS: sampling range(len) draws the same entries, with the same
     # consumption of the `random` stream, as sampling the sequence itself
@@ -581,19 +602,34 @@ def load_data(model_path, dataset_path):
         rank, world = parallel.world()
         with open(dataset_path, 'rb') as f:
             loaded = pickle.load(f)
-        shards = sorted(glob.glob(glob.escape(dataset_path) + '.rank*of*'))
-        own = dataset_path + '.rank{}of{}'.format(rank, world)
-        if world > 1 and len(shards) == world - 1 and (rank == 0 or own in shards):
-            # written by a job of this shape: every rank takes its own shard back
-            if rank > 0:
-                with open(own, 'rb') as f:
+        # shard files beside it, by their parsed suffix: {written world size: {rank: path}}
+        import re
+        found = {}
+        for sp in glob.glob(glob.escape(dataset_path) + '.rank*of*'):
+            m = re.fullmatch(r'\.rank(\d+)of(\d+)', sp[len(dataset_path):])
+            if m:
+                found.setdefault(int(m.group(2)), {})[int(m.group(1))] = sp
+        # the same decision on every rank, from the file names alone: the shards of a job of THIS shape are there
+        # (ranks 1 .. world-1 of `world`, nothing left over from a job of another size)
+        same_shape = world > 1 and list(found) == [world] and sorted(found[world]) == list(range(1, world))
+        if same_shape:
+            if rank > 0:                                  # every rank takes its own shard back
+                with open(found[world][rank], 'rb') as f:
                     loaded = pickle.load(f)
-        elif world > 1 or shards:
-            # another shape (or a single-process file): pool what there is and deal it out entry i -> rank i % world
-            pool = list(loaded)
-            for sp in shards:
-                with open(sp, 'rb') as f:
-                    pool.extend(pickle.load(f))
+        elif world > 1 or found:
+            # another shape (or a single-process file next to stale shards): pool rank 0's file with the newest shard set and
+            # deal it out. The shards are interleaved round robin (entry i of every shard before entry i + 1 of any), so
+            # a memory that has to be cut to MEMORY_SIZE loses the OLDEST entries of every shard alike, not one rank's.
+            parts = [list(loaded)]
+            if found:
+                w = max(found, key=lambda k: max(os.path.getmtime(q) for q in found[k].values()))   # the newest set
+                for r in sorted(found[w]):
+                    with open(found[w][r], 'rb') as f:
+                        parts.append(list(pickle.load(f)))
+            longest = max(len(q) for q in parts)
+            # right-aligned interleave: the newest entries of all shards end up at the end of the pool
+            pool = [q[i - (longest - len(q))] for i in range(longest) for q in parts if i >= longest - len(q)]
+            pool = pool[max(0, len(pool) - MEMORY_SIZE * world):]
             loaded = pool[rank::world]
         if hasattr(rep_memory, "extend_augmented"):
             rep_memory.clear()
@@ -621,14 +657,16 @@ def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, sa
         logging.warning(' ' * 20 + '  {:2} Iteration  '.format(n_iter) + ' ' * 20)
         logging.warning('=' * 58)
         if n_iter > 0:
-            self_play(parallel.world()[1])                # the reference's one game -- on every GPU
+            # the reference's one game -- on every GPU; GAMES_PER_ITER games (over all ranks) when set
+            self_play(parallel.world()[1] if GAMES_PER_ITER is None else int(GAMES_PER_ITER))
             train(N_EPOCHS, n_iter)
         else:
             self_play(n_first)
         if n_iter % save_every == 0:
+            today = parallel.agree(int(datetime.now().strftime('%y%m%d')), "max", device)   # one file-name date for all ranks
             if parallel.world()[0] == 0:
-                save_model(Agent, n_iter + save_every, step, directory)
-            save_dataset(rep_memory, n_iter + save_every, step, directory)   # every rank: its own shard
+                save_model(Agent, n_iter + save_every, step, directory, '{:06d}'.format(today))
+            save_dataset(rep_memory, n_iter + save_every, step, directory, '{:06d}'.format(today))   # every rank: its own shard
         reset_iter(result, cur_memory)
         done += 1
     return done

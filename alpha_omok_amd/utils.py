@@ -67,34 +67,44 @@ def get_state_pt(node_id, board_size, channel_size):
     return planes.reshape(channel_size, board_size, board_size)
 
 
-def states_of_episodes(moves, lengths, ep_of, ply_of, board_size, channel_size, dtype=np.float64):
+def states_of_episodes(moves, ep_of, ply_of, board_size, channel_size, dtype=np.float64, chunk=256):
     """get_state_pt for MANY positions at once: sample i is the root (0, m_1, ..., m_t) of episode ep_of[i] after
-    t = ply_of[i] of its moves (moves [E, L] int, -1 padded; lengths [E]). Returns [N, C, B, B] of `dtype`, equal
-    entry for entry to np.stack([get_state_pt(...)]) (utils.py:139-168) -- cumulative stone sets per colour, then
-    one gather per history plane instead of a Python call per sample."""
+    t = ply_of[i] of its moves (moves [E, L] int, -1 padded). Returns [N, C, B, B] of `dtype`, equal entry for entry
+    to np.stack([get_state_pt(...)]) (utils.py:139-168) -- cumulative stone sets per colour, then one gather per
+    history plane instead of a Python call per sample. Episodes are processed `chunk` at a time, so the temporaries
+    (one-hot and cumulative stone sets, [chunk, L, A] bytes each) stay at a few MB whatever E is."""
     moves = np.asarray(moves, dtype=np.int64)
     ep_of = np.asarray(ep_of, dtype=np.int64)
     ply_of = np.asarray(ply_of, dtype=np.int64)
     E, L = moves.shape
     A = board_size * board_size
     N = ep_of.shape[0]
-    # cum[c, e, j] = stones of colour c (0 black: even move index) after the first j+1 moves of episode e
-    onehot = np.zeros((E, L, A), np.uint8)
-    ee, jj = np.nonzero(moves >= 0)
-    onehot[ee, jj, moves[ee, jj]] = 1
-    cum = np.zeros((2, E, L, A), np.uint8)
-    par = (np.arange(L) % 2)[None, :, None]
-    cum[0] = np.cumsum(onehot * (par == 0), axis=1, dtype=np.uint8)
-    cum[1] = np.cumsum(onehot * (par == 1), axis=1, dtype=np.uint8)
     out = np.zeros((N, channel_size, A), dtype)
-    for j in range(channel_size - 1):
-        p = ply_of - j                        # X_p: the mover of (1-based) ply p after that ply; black moves the odd plies
-        ok = p >= 1
-        idx = np.flatnonzero(ok)
-        if idx.size:
-            pp = p[idx]
-            out[idx, channel_size - 2 - j] = cum[(pp - 1) % 2, ep_of[idx], pp - 1]
     out[:, channel_size - 1, :] = (ply_of % 2 == 0).astype(dtype)[:, None]
+    if N == 0:
+        return out.reshape(N, channel_size, board_size, board_size)
+    by_ep = np.argsort(ep_of, kind="stable")              # (already sorted when the samples come from main.self_play)
+    bounds = np.searchsorted(ep_of[by_ep], np.arange(0, E + chunk, chunk))
+    par = (np.arange(L) % 2)[None, :, None]
+    for c, e0 in enumerate(range(0, E, chunk)):
+        sel = by_ep[bounds[c]:bounds[c + 1]]
+        if sel.size == 0:
+            continue
+        mv = moves[e0:e0 + chunk]
+        # cum[col, e, j] = stones of colour col (0 black: even move index) after the first j+1 moves of episode e0 + e
+        onehot = np.zeros((mv.shape[0], L, A), np.uint8)
+        ee, jj = np.nonzero(mv >= 0)
+        onehot[ee, jj, mv[ee, jj]] = 1
+        cum = np.empty((2,) + onehot.shape, np.uint8)
+        np.cumsum(onehot * (par == 0), axis=1, dtype=np.uint8, out=cum[0])
+        np.cumsum(onehot * (par == 1), axis=1, dtype=np.uint8, out=cum[1])
+        e_loc, t = ep_of[sel] - e0, ply_of[sel]
+        for j in range(channel_size - 1):
+            p = t - j                         # X_p: the mover of (1-based) ply p after that ply; black moves the odd plies
+            ok = np.flatnonzero(p >= 1)
+            if ok.size:
+                pp = p[ok]
+                out[sel[ok], channel_size - 2 - j] = cum[(pp - 1) % 2, e_loc[ok], pp - 1]
     return out.reshape(N, channel_size, board_size, board_size)
 
 

@@ -32,6 +32,28 @@ def test_utils_planes_board_turn_golden():
         assert utils.get_turn(nid) == int(g["t%d" % i])
 
 
+def test_states_of_episodes_equals_get_state_pt_per_sample():
+    """main.self_play builds the states of all samples of a call at once (utils.states_of_episodes, episodes in chunks):
+    entry for entry get_state_pt (utils.py:139-168), for samples in any order, across chunk boundaries, empty input."""
+    from alpha_omok_amd import utils
+    rng = np.random.default_rng(0)
+    B, A, E = 9, 81, 300
+    moves = np.full((E, A), -1, np.int32)
+    lengths = rng.integers(1, A + 1, E)
+    for e in range(E):
+        moves[e, :lengths[e]] = rng.permutation(A)[:lengths[e]]
+    ep = np.concatenate([np.full(lengths[e], e) for e in range(E)])
+    pl = np.concatenate([np.arange(lengths[e]) for e in range(E)])
+    pick = rng.permutation(ep.size)[:1200]
+    for chunk in (7, 256):
+        out = utils.states_of_episodes(moves, ep[pick], pl[pick], B, 5, chunk=chunk)
+        assert out.shape == (pick.size, 5, B, B) and out.dtype == np.float64
+        for k, i in enumerate(pick):
+            rid = (0,) + tuple(int(x) for x in moves[ep[i], :pl[i]])
+            assert np.array_equal(out[k], utils.get_state_pt(rid, B, 5)), (chunk, k)
+    assert utils.states_of_episodes(moves, ep[:0], pl[:0], B, 5).shape == (0, 5, B, B)
+
+
 def test_utils_legal_order_golden():
     from alpha_omok_amd import utils
     g = load_golden("gv2_legal_order")
