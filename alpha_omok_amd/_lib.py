@@ -66,6 +66,7 @@ SYMBOLS = {
     "ao_tree_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
     "ao_trim_stats": (C.c_int, [_vp, _i64p, _i64p]),
     "ao_node_cap": (C.c_int, [_vp, _i32p, _i32p]),
+    "ao_host_threads": (C.c_int, []),
     "ao_fp16_range_events": (C.c_int, [_vp, _i64p, _i64p]),
     "ao_search_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "ao_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(_vp)]),

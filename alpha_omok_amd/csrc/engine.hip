@@ -35,6 +35,8 @@ void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
                    hipStream_t s, int in_kind, int parts);
 int net_step_params(ao_net* n, int boards, float* policy, float* value, StepNet* out);
+void net_fp16_fallback_begin(ao_net* n);
+int net_fp16_fallback_end(ao_net* n);
 // step_kernels.hip
 void launch_step_board(const TreeParams& p, const StepNet& f, int rows, const int32_t* game_of_row, hipStream_t s);
 void net_plan(const ao_net* n, int boards, int* group, int* nchq, int* kind);
@@ -503,19 +505,10 @@ int ao_begin_move(ao_engine* e, const uint8_t* active) {
                 r.dirichlet(alpha, k, e->h_noise + static_cast<size_t>(g) * Ap);
             }
         };
-        unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
-        if (G < 64) nt = 1;
-        if (nt <= 1) {
-            work(0, G);
-        } else {
-            std::vector<std::thread> th;
-            const int per = (G + static_cast<int>(nt) - 1) / static_cast<int>(nt);
-            for (unsigned t = 0; t < nt; ++t) {
-                const int g0 = static_cast<int>(t) * per, g1 = std::min(G, g0 + per);
-                if (g0 < g1) th.emplace_back(work, g0, g1);
-            }
-            for (auto& t : th) t.join();
-        }
+        // the process's persistent host pool (host_rng.hpp: hardware threads / LOCAL_WORLD_SIZE, at most 32); games in
+        // chunks of 16 so that the ranks of a node do not oversubscribe the host at the start of every move
+        if (G < 64) work(0, G);
+        else ao::HostPool::get().run(G, 16, work);
         AO_HIP(e, hipMemcpyAsync(p.mt, e->h_mt, sizeof(uint32_t) * 624 * G, hipMemcpyHostToDevice, e->stream));
         AO_HIP(e, hipMemcpyAsync(p.mtpos, e->h_pos, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
         AO_HIP(e, hipMemcpyAsync(p.noise_buf, e->h_noise, sizeof(double) * G * Ap, hipMemcpyHostToDevice, e->stream));
@@ -729,9 +722,10 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // move get their pre-move MT19937 streams back and FRESH trees at their current positions (ao_set_roots semantics:
     // what the search inherited from earlier moves is forgotten -- the one deviation from the reference, which would
     // have searched on top of its inherited counts), the caller gets a result instead of an exception and the event is
-    // counted (ao_fp16_range_events; the Python layer turns it into a warning). The network returns to its previous
-    // mode afterwards; from the third event on it stays on the fp32-MFMA trunk (a checkpoint that keeps leaving the
-    // range would otherwise search every move twice).
+    // counted (ao_fp16_range_events; the Python layer turns it into a warning). The network returns to its requested
+    // mode afterwards; from the third event of the SAME weights on (counted per network object since its last
+    // ao_net_finalize) it stays on the fp32-MFMA trunk -- a checkpoint that keeps leaving the range would otherwise search
+    // every move twice -- until new weights are loaded or ao_net_set_mode is called.
     int32_t nflags = 0;
     if (ao_net_status(net, e->stream, &nflags, 1)) return e->fail(std::string("ao_net_status: ") + ao_net_last_error(net));
     if (nflags & AO_NET_FP16_RANGE) {
@@ -760,12 +754,11 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         e->gauss = e->gauss_backup;
         if (ao_reset(e, mask.data())) return 1;
         if (set_roots_impl(e, static_cast<int>(games.size()), games.data(), ids.data(), ns.data(), nullptr)) return 1;
-        const int prev_mode = ao_net_get_mode(net);
-        ao_net_set_mode(net, 2);
+        ao::net_fp16_fallback_begin(net);                // mode 2 for the repeated move
         ++e->fp16_events;
         e->fp16_games_redone += static_cast<int64_t>(games.size());
         const int rc2 = search_impl(e, net, active, tau, pi, visit, policy, false);
-        if (e->fp16_events < 3) ao_net_set_mode(net, prev_mode);
+        ao::net_fp16_fallback_end(net);                  // back to the requested mode, unless these weights did it three times
         return rc2;
     }
     return ao_end_move(e, tau, pi, visit, policy);
@@ -781,6 +774,8 @@ int ao_fp16_range_events(ao_engine* e, int64_t* moves_repeated, int64_t* games_r
     if (games_redone) *games_redone = e->fp16_games_redone;
     return 0;
 }
+
+int ao_host_threads(void) { return static_cast<int>(ao::HostPool::budget()); }
 
 int ao_node_cap(ao_engine* e, int32_t* node_cap, int32_t* from_free_memory) {
     if (node_cap) *node_cap = e->cfg.node_cap;

@@ -8,8 +8,18 @@
 //
 // Follows numpy 2.2.6: random/src/mt19937/mt19937.c, random/src/legacy/legacy-distributions.c.
 #pragma once
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 namespace ao {
 
@@ -114,6 +124,117 @@ struct HostMT {
             for (int j = 0; j < k; ++j) out[j] *= inv;
         }
     }
+};
+
+// The host threads that replay the Dirichlet draws of all games at the start of a move (ao_begin_move): ONE persistent
+// pool per process, created on first use, instead of a std::thread spawn per move.
+//
+// Per-rank budget. With one process per GPU, eight ranks share the host: the pool takes
+// hardware_concurrency / LOCAL_WORLD_SIZE threads (torchrun exports LOCAL_WORLD_SIZE; 1 without a launcher), at most 32,
+// at least 1; AO_HOST_THREADS overrides. The calling thread works too, so `threads()` - 1 workers are parked on a
+// condition variable between moves. Work is handed out in chunks through one atomic counter.
+class HostPool {
+  public:
+    static HostPool& get() {
+        static HostPool* pool = new HostPool();   // never destroyed: no join at interpreter exit, the workers end with the process
+        pool->after_fork();
+        return *pool;
+    }
+
+    static unsigned budget() {
+        if (const char* v = std::getenv("AO_HOST_THREADS")) {
+            const long n = std::strtol(v, nullptr, 10);
+            if (n >= 1) return static_cast<unsigned>(std::min<long>(n, 256));
+        }
+        long ranks = 1;
+        if (const char* v = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max<long>(1, std::strtol(v, nullptr, 10));
+        const long hw = std::max<long>(1, static_cast<long>(std::thread::hardware_concurrency()));
+        return static_cast<unsigned>(std::min<long>(32, std::max<long>(1, hw / ranks)));
+    }
+
+    unsigned threads() const { return nthreads_; }
+
+    // fn(i0, i1) over [0, n) in chunks of `chunk`; returns when every chunk is done. Not re-entrant (one caller at a time:
+    // an engine handle is single-threaded, and engines of one process take turns on the mutex).
+    void run(int n, int chunk, const std::function<void(int, int)>& fn) {
+        if (n <= 0) return;
+        if (nthreads_ <= 1 || n <= chunk) {
+            fn(0, n);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(run_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            chunk_ = chunk;
+            next_.store(0, std::memory_order_relaxed);
+            busy_ = static_cast<int>(workers_.size());
+            ++generation_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    HostPool() { start(); }
+
+    void start() {
+        pid_ = getpid();
+        nthreads_ = budget();
+        workers_.clear();
+        for (unsigned t = 1; t < nthreads_; ++t) workers_.emplace_back([this] { worker(); });
+        for (auto& w : workers_) w.detach();
+    }
+
+    void after_fork() {
+        // a forked child inherits the object but none of its threads: start over there (the old vector of detached
+        // handles holds nothing to join)
+        if (pid_ != getpid()) {
+            new (&mu_) std::mutex();
+            new (&run_mu_) std::mutex();
+            new (&cv_) std::condition_variable();
+            new (&done_cv_) std::condition_variable();
+            generation_ = 0;
+            busy_ = 0;
+            start();
+        }
+    }
+
+    void drain() {
+        for (;;) {
+            const int i0 = next_.fetch_add(chunk_, std::memory_order_relaxed);
+            if (i0 >= n_) break;
+            (*fn_)(i0, std::min(n_, i0 + chunk_));
+        }
+    }
+
+    void worker() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            drain();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--busy_ == 0) done_cv_.notify_one();
+        }
+    }
+
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, chunk_ = 1, busy_ = 0;
+    uint64_t generation_ = 0;
+    unsigned nthreads_ = 1;
+    pid_t pid_ = 0;
 };
 
 }  // namespace ao

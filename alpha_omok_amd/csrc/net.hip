@@ -34,6 +34,9 @@ struct ao_net {
     int nchq16 = 0;  // ... of the group-resident path (groups of 16 boards): multiple of 8
     int CQ = 0;
     int mode = 0;    // 0 auto, 1 layer kernels (32), 2 group-resident trunk, 3 per-board, 4 row-chunked layers (16)
+    int requested_mode = 0;  // what ao_net_set_mode asked for; `mode` differs only while the fp16-range fallback holds the net on 2
+    int fp16_fallbacks = 0;  // moves the engine repeated on the fp32-MFMA trunk since these weights were loaded (ao_net_finalize)
+    bool forced_fp32 = false;
     int num_cu = 256;
     bool finalized = false;
     std::string err;
@@ -705,9 +708,26 @@ int ao_net_set_mode(ao_net* n, int mode) {
                        "or 6 (split-fp16 per-layer kernels for every batch size)");
     if ((mode == 5 || mode == 6) && !h16_supported(n))
         return n->fail("modes 5 / 6 (split-fp16 MFMA trunk) need 128 planes and at least one ResBlock");
-    n->mode = mode;
+    n->mode = n->requested_mode = mode;
+    n->forced_fp32 = false;
     return 0;
 }
+
+namespace ao {
+// The engine's fp16-range recovery (ao_search): the move is repeated on the fp32-MFMA trunk (mode 2). The fallback
+// belongs to the WEIGHTS that overflowed: it is counted per network object since its last ao_net_finalize; from the
+// third repeated move on the network stays on the fp32-MFMA trunk -- until new weights are loaded (ao_net_finalize
+// returns it to the mode ao_net_set_mode asked for) or ao_net_set_mode is called again.
+void net_fp16_fallback_begin(ao_net* n) {
+    ++n->fp16_fallbacks;
+    n->mode = 2;
+}
+int net_fp16_fallback_end(ao_net* n) {
+    n->forced_fp32 = n->fp16_fallbacks >= 3;
+    if (!n->forced_fp32) n->mode = n->requested_mode;
+    return n->forced_fp32 ? 1 : 0;
+}
+}  // namespace ao
 
 int ao_net_get_mode(const ao_net* n) { return n->mode; }
 
@@ -787,6 +807,9 @@ int ao_net_finalize(ao_net* n) {
     NET_HIP(n, hipSetDevice(n->device));
     NET_HIP(n, hipDeviceSynchronize());   // nothing may still read the buffers that are overwritten below
     n->pcursor = 0;
+    n->fp16_fallbacks = 0;                // new weights: what the old ones did to the fp16 range says nothing about these
+    n->forced_fp32 = false;
+    n->mode = n->requested_mode;
     n->conv_w.clear(); n->conv_sc.clear(); n->conv_sh.clear();
     n->convh_wh.clear(); n->convh_wl.clear(); n->convh_sc.clear();
     if (param_alloc(n, &n->d_status, 4)) return 1;

@@ -97,6 +97,11 @@ class Net:
         kernels for every batch size (a position's evaluation then does not depend on what else is in the batch)."""
         self._check(self._L.ao_net_set_mode(self._h, int(mode)), "ao_net_set_mode")
 
+    def get_mode(self):
+        """The mode in force: what set_mode asked for, or 2 while the fp16-range fallback holds the network on the
+        fp32-MFMA trunk (three repeated moves with the same weights; ends with the next load_state_dict / set_mode)."""
+        return int(self._L.ao_net_get_mode(self._h))
+
     def status(self, clear=True, stream=None):
         """Status word (ao_net_status): bit 0 = an activation left the fp16 range in the split-fp16 trunk since
         the last clear (those forwards were clamped, not fp32-equivalent). Synchronises `stream`."""
@@ -258,8 +263,10 @@ class Engine:
         if ev != self._fp16_seen:
             import warnings
             warnings.warn("the split-fp16 trunk met an activation beyond the fp16 range (|x| > 65504): this move was searched "
-                          "again on the fp32-MFMA trunk with fresh trees for its %d games (%d such move(s) so far; from the "
-                          "third on the network stays on the fp32-MFMA trunk)" % (games - self._fp16_games_seen, ev),
+                          "again on the fp32-MFMA trunk with fresh trees for its %d games (%d such move(s) of this engine so far). "
+                          "From the third such move of the SAME weights on, the network stays on the fp32-MFMA trunk -- also "
+                          "when mode 6 (reproducible=True) had been asked for -- until new weights are loaded or set_mode is "
+                          "called; Net.get_mode() tells which kernels run" % (games - self._fp16_games_seen, ev),
                           RuntimeWarning, stacklevel=2)
             self._fp16_seen, self._fp16_games_seen = ev, games
         return pi, vis, pol

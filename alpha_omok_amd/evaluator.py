@@ -49,8 +49,7 @@ class Evaluator:
                 self._net = Net(cfg[0], cfg[1], cfg[2], cfg[3], self.device)
                 self._cfg = cfg
             self._net.load_state_dict(model.state_dict())
-            if self.net_mode:
-                self._net.set_mode(self.net_mode)
+            self._net.set_mode(self.net_mode)             # after every export, 0 included: an fp16-range fallback of the OLD weights ends here
             self._key = (cfg, version)
             try:
                 self._ref = weakref.ref(model)

@@ -451,12 +451,13 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     return dict(episodes=len(episodes), moves=int(n_new), **trim_stats)
 
 
-def train_batch(batch):
+def train_batch(batch, total=None):
     """One optimiser step of main.py:283-305 on `batch` (entries of rep_memory, or positions in it when
     rep_memory lives on the device; an EMPTY batch means this rank has nothing for this step and only
     takes part in the collective). Local forward/backward, one all-reduce of the flattened gradient over
-    the ranks (none with one process), Adam step. Returns (loss, v_loss, p_loss) or None for an empty
-    batch; `step` advances whenever any rank contributed."""
+    the ranks (none with one process), Adam step. `total`: the number of samples ALL ranks put behind this step,
+    when the caller knows it (train() does, from one agreement per pass) -- the all-reduce then needs no read-back.
+    Returns (loss, v_loss, p_loss) or None for an empty batch; `step` advances whenever any rank contributed."""
     global step
     import torch
     optimizer.zero_grad()
@@ -474,7 +475,7 @@ def train_batch(batch):
         loss = v_loss + p_loss
         loss.backward()
     # each rank's gradient counts for the samples behind it (a shard that ran short contributes a partial batch)
-    _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0, weight=len(batch))
+    _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0, weight=len(batch), total=total)
     if contributors == 0:
         return None
     optimizer.step()
@@ -520,10 +521,15 @@ def train(n_epochs, n_iter):
     logging.warning('train memory size: {}'.format(len(train_memory)))
     losses = []
     trained = False
+    # the samples all ranks together put behind each mini-batch of the pass: one small all-reduce here instead of a
+    # device read-back inside every gradient all-reduce
+    totals = [None] * n_steps
+    if world > 1:
+        totals = parallel.agree_sums([len(train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]) for i in range(n_steps)], device)
     for epoch in range(n_epochs):
         for i in range(n_steps):
             batch = train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]
-            out = train_batch(batch)
+            out = train_batch(batch, totals[i])
             if out is not None:
                 trained = True
                 losses.append(out)

@@ -90,16 +90,44 @@ def agree(value, op="max", device=None):
     return int(t.item())
 
 
-def allreduce_gradients(module, contributes=True, weight=1.0):
+def agree_sums(values, device=None):
+    """Element-wise sum over the ranks of a list of integers (ONE all-reduce); the list itself without a process group.
+    main.train uses it once per pass to learn, for every mini-batch of the pass, how many samples ALL ranks will put
+    behind it -- so the per-mini-batch gradient all-reduce needs no host read-back to find its divisor."""
+    import torch.distributed as dist
+    vals = [int(v) for v in values]
+    if not _collectives_on() or not vals:
+        return vals
+    t = torch.tensor(vals, dtype=torch.int64, device=device or "cpu")
+    if dist.get_backend() == "nccl" and not t.is_cuda:
+        t = t.cuda()
+    dist.all_reduce(_staged_inplace(t), op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def _staged_inplace(t):
+    """`t` itself where the backend can reduce it in place (nccl on device memory, gloo on host memory)."""
+    import torch.distributed as dist
+    assert not (dist.get_backend() == "gloo" and t.is_cuda)
+    return t
+
+
+def allreduce_gradients(module, contributes=True, weight=1.0, total=None):
     """grad <- weighted mean over the CONTRIBUTING ranks, through ONE flattened fp32 buffer (ncclAllReduce(sum)).
 
     Every rank calls this once per mini-batch, whether or not it had a batch of its own: a rank without
     one (empty replay shard, fewer samples than the agreed step count) passes contributes=False and adds
     zeros. `weight` is the number of samples behind this rank's gradient (main.train_batch passes len(batch)): the
-    local gradient -- a mean over the local batch -- is scaled by it and the last element of the buffer carries the
-    weights' sum, so the result is the gradient of the mean loss over the UNION of the ranks' batches and a rank whose
-    shard ran short (a partial batch) counts for what it holds, not for a full share. The divisor travels in the same
-    message. Returns (elements reduced, summed weight: the number of contributing ranks when every weight is 1);
+    local gradient -- a mean over the local batch -- is scaled by it, so the result is the gradient of the mean loss
+    over the UNION of the ranks' batches and a rank whose shard ran short (a partial batch) counts for what it holds,
+    not for a full share.
+
+    The divisor (the weights' sum over the ranks). `total` given: the caller already knows it (main.train agrees on the
+    whole pass's batch sizes up front with ONE agree_sums), the buffer is divided by that number and nothing is read
+    back from the device -- the RCCL all-reduce, the division and the copy into .grad are all enqueued and the host runs
+    ahead. `total` None: the weights' sum travels as one extra element of the same message and is read back (a host
+    synchronisation per call: the convenience form, for callers that do not know their peers' batch sizes).
+    Returns (elements reduced, summed weight: the number of contributing ranks when every weight is 1);
     without a process group it is a no-op."""
     import torch.distributed as dist
     params = [p for p in module.parameters() if p.requires_grad]
@@ -111,7 +139,8 @@ def allreduce_gradients(module, contributes=True, weight=1.0):
         parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]
     else:
         parts = [torch.zeros(p.numel(), dtype=p.dtype, device=dev) for p in params]
-    parts.append(torch.full((1,), 1.0, dtype=parts[0].dtype, device=dev))
+    if total is None:
+        parts.append(torch.full((1,), 1.0, dtype=parts[0].dtype, device=dev))
     flat = torch.cat(parts)
     if weight != 1.0:
         flat.mul_(weight)                                 # (the trailing 1 becomes the weight)
@@ -119,7 +148,12 @@ def allreduce_gradients(module, contributes=True, weight=1.0):
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     if buf is not flat:
         flat.copy_(buf)
-    total = float(flat[-1].item())
+    if total is None:
+        total = float(flat[-1].item())
+        n_el = flat.numel() - 1
+    else:
+        total = float(total)
+        n_el = flat.numel()
     count = int(round(total)) if abs(total - round(total)) < 1e-3 else total
     if total > 0:
         flat.div_(total)
@@ -132,7 +166,7 @@ def allreduce_gradients(module, contributes=True, weight=1.0):
         else:
             p.grad.copy_(g)
         off += k
-    return flat.numel() - 1, count
+    return n_el, count
 
 
 def average_buffers(module, contributes=True):
@@ -154,15 +188,16 @@ def average_buffers(module, contributes=True):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         if buf is not flat:
             flat.copy_(buf)
-        count = int(round(float(flat[-1].item())))
-        if count > 0:
-            flat.div_(count)
-            off = 0
-            with torch.no_grad():
-                for b in fl:
-                    k = b.numel()
-                    b.copy_(flat[off:off + k].view_as(b))
-                    off += k
+        # divide on the device by the count that travelled in the message; with no contributor at all every rank
+        # keeps what it has (the select below), and nothing is read back to the host
+        cnt = flat[-1]
+        avg = flat / cnt.clamp_min(1.0)
+        off = 0
+        with torch.no_grad():
+            for b in fl:
+                k = b.numel()
+                b.copy_(torch.where(cnt > 0, avg[off:off + k].view_as(b).to(b.dtype), b))
+                off += k
     if it:
         flat = torch.cat([b.detach().reshape(-1).to(torch.int64) for b in it])
         buf = _staged(flat)

@@ -300,13 +300,17 @@ class TrainStep:
         M.Agent.model.train()
         self.numel = sum(p.numel() for p in M.Agent.model.parameters())
         self.ms, self.export_ms, self.losses = [], [], []
+        # the samples all ranks put behind a step, agreed ONCE (the shards do not change during the bench): the per-step
+        # gradient all-reduce then reads nothing back from the device (parallel.allreduce_gradients, `total`)
+        from alpha_omok_amd import parallel
+        self.total = parallel.agree_sums([min(M.BATCH_SIZE, len(M.rep_memory))], torch.device("cuda", local))[0] if world > 1 else None
 
     def step(self, record):
         M = self.M
         t0 = time.perf_counter()
         n = len(M.rep_memory)
         batch = self.random.sample(range(n), min(M.BATCH_SIZE, n))
-        out = M.train_batch(batch)
+        out = M.train_batch(batch, self.total)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         self.net.load_state_dict(M.Agent.model.state_dict())
@@ -342,6 +346,16 @@ class TrainStep:
              "allreduce_ms_isolated": self.allreduce_probe(dist, dev),
              "replay_entries_per_gpu": len(M.rep_memory), "mean_loss": float(np.mean(self.losses)) if self.losses else None,
              "inside_timed_region": True}
+        # every rank applied the same all-reduced gradient with the same Adam state: the weights must still be
+        # bit-identical across the ranks (two 64-bit checksums of the parameter BITS, gathered over the group)
+        if dist is not None:
+            bits = torch.cat([p.detach().reshape(-1) for p in M.Agent.model.parameters()]).view(torch.int32).to(torch.int64)
+            idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+            mine = torch.stack([bits.sum(), (bits * (idx % 8191)).sum()])
+            mine = mine if dist.get_backend() == "nccl" else mine.cpu()
+            got = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(got, mine)
+            r["weights_identical_across_ranks"] = bool(all(torch.equal(g, got[0]) for g in got))
         if self.ms:
             r["share_of_step"] = (float(np.mean(self.ms)) + float(np.mean(self.export_ms))) / ms_per_step
         return r
@@ -551,6 +565,7 @@ def main():
                 "games_per_gpu": G, "sims": S, "board": B, "n_block": args.blocks, "planes": args.planes,
                 "parallelism": "games sharded over %d GPU(s), no data-path collective in self-play%s" % (
                     world, "; one gradient all-reduce per training step" if train_on else ""),
+                "host_threads_per_rank": int(__import__("alpha_omok_amd._lib", fromlist=["load"]).load().ao_host_threads()),
                 "mean_select_depth": counters["levels"] / sims_total,
                 "terminal_leaf_fraction": counters["terminal"] / sims_total,
                 "games_finished": counters["games"],

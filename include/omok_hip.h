@@ -141,9 +141,17 @@ int ao_trim_stats(ao_engine *e, int64_t *subtrees_dropped, int64_t *reroots_trim
 /* the arena capacity this engine runs with (ao_config.node_cap after defaults) and whether it was derived from the free
  * HBM at creation (node_cap = -1): what decides if agents.py's never-pruned dict (agents.py:52) is reproduced in full. */
 int ao_node_cap(ao_engine *e, int32_t *node_cap, int32_t *from_free_memory);
+/* Host threads this PROCESS uses for the per-move np.random.dirichlet replay (agents.py:97-98,194-195 need glibc log / pow,
+ * so the draws of all games are made on the host at the start of a move): one persistent pool per process of
+ * min(32, hardware threads / LOCAL_WORLD_SIZE) threads, the caller included (LOCAL_WORLD_SIZE as torchrun exports it: the
+ * ranks of a node share the host; AO_HOST_THREADS overrides). Needs no device. */
+int ao_host_threads(void);
 /* ao_search repeats a move on the fp32-MFMA trunk when the split-fp16 trunk met an activation beyond the fp16 range
  * (ao_net_status): the games of that move get their pre-move streams back and fresh trees at their positions, the
- * caller gets the repeated move's result. Counted here since ao_create: moves repeated, games searched again. */
+ * caller gets the repeated move's result. Counted here since ao_create: moves repeated, games searched again. The
+ * network returns to the mode ao_net_set_mode asked for after the repeated move; from the third such move with the SAME
+ * weights (counted per ao_net since its last ao_net_finalize) it stays on the fp32-MFMA trunk -- ao_net_get_mode then says
+ * 2 -- until new weights are finalized or ao_net_set_mode is called. */
 int ao_fp16_range_events(ao_engine *e, int64_t *moves_repeated, int64_t *games_redone);
 /* search-shape counters since the last ao_begin_move, summed over games: PUCT levels traversed,
  * k>1 random tie-breaks, terminal leaves, evaluated leaves */

@@ -30,3 +30,22 @@ def test_create_fails_loudly_without_gpu():
     from alpha_omok_amd.engine import Engine, EngineError
     with pytest.raises(EngineError):
         Engine(9, 10, 5, games=1)
+
+
+def test_host_thread_budget_follows_local_world_size():
+    """ao_host_threads: the per-process pool for the per-move Dirichlet replay is hardware threads / LOCAL_WORLD_SIZE
+    (torchrun's variable: the ranks of a node share the host), at most 32, at least 1; AO_HOST_THREADS overrides."""
+    import subprocess
+    import sys
+    hw = os.cpu_count() or 1
+    code = "from alpha_omok_amd import _lib; print(_lib.load(build_if_missing=False).ao_host_threads())"
+
+    def ask(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "AO_HOST_THREADS")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code], env=e, cwd=REPO, capture_output=True, text=True,
+                                  check=True).stdout.strip().splitlines()[-1])
+
+    assert ask() == max(1, min(32, hw))
+    assert ask(LOCAL_WORLD_SIZE="8") == max(1, min(32, hw // 8))
+    assert ask(LOCAL_WORLD_SIZE="8", AO_HOST_THREADS="3") == 3

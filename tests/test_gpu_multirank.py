@@ -247,3 +247,32 @@ def test_bench_self_launches_two_ranks_with_training_step(tmp_path):
     ts = d["train_step"]
     assert ts["allreduce_ranks"] == 2 and ts["allreduce_backend"] == "gloo" and ts["train_steps"] == 2 and ts["inside_timed_region"]
     assert ts["allreduce_elements"] > 1000 and ts["mean_loss"] is not None and np.isfinite(ts["mean_loss"])
+
+
+def test_bench_eight_rank_launch_shape_on_the_shared_gpu(tmp_path):
+    """The driver's 8-GPU command shape (`bench.py --gpus 8`: eight ranks, the configs[3] training step with its gradient
+    all-reduce after every step) at tiny sizes on this 1-GPU box -- the ranks share cuda:0, the collectives run over gloo.
+    What it pins before an 8-GPU node ever sees the code: ONE JSON line from rank 0 with n_gpus = 8, all eight ranks'
+    move decisions in `value`, no deadlock in agree_sums / allreduce_gradients / the barriers with eight participants,
+    bit-identical weights on every rank after the training steps, and the per-rank host-thread budget
+    (LOCAL_WORLD_SIZE = 8 as torchrun exports it)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AO_BENCH_SHARE_GPU="1", AO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--games", "32",
+           "--sims", "8", "--blocks", "1", "--prefill-games", "2", "--prefill-sims", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %r" % r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(8 * 32 * 2 / (d["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    ts = d["train_step"]
+    assert ts["allreduce_ranks"] == 8 and ts["train_steps"] == 2 and ts["inside_timed_region"]
+    assert ts["weights_identical_across_ranks"] is True
+    assert ts["mean_loss"] is not None and np.isfinite(ts["mean_loss"])
+    assert d["config"]["host_threads_per_rank"] == max(1, min(32, (os.cpu_count() or 1) // 8))

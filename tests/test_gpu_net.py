@@ -344,6 +344,14 @@ def test_split_fp16_trunk_reports_activations_beyond_fp16_range(batch):
         rp, rv = ref(x.cpu())
     p2, v2 = net(x)
     assert np.abs(p2.cpu().numpy() - rp.numpy()).max() < TOL and np.abs(v2.cpu().numpy() - rv.numpy()).max() < TOL
+    # the fallback belongs to the weights that overflowed: loading other weights returns the network to the mode that was
+    # asked for (0 here), and a search with them raises no event
+    assert net.get_mode() == 2
+    net.load_state_dict(sd)
+    assert net.get_mode() == 0
+    eng.reset()
+    eng.search(net, tau=1)
+    assert eng.fp16_range_events() == (3, 3 * batch) and net.get_mode() == 0
     for en in (eng, eng2):
         en.close()
 
