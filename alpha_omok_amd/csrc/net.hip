@@ -654,6 +654,22 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
 
 }  // namespace ao
 
+namespace ao {
+// The engine's fp16-range recovery (ao_search): the move is repeated on the fp32-MFMA trunk (mode 2). The fallback
+// belongs to the WEIGHTS that overflowed: it is counted per network object since its last ao_net_finalize; from the
+// third repeated move on the network stays on the fp32-MFMA trunk -- until new weights are loaded (ao_net_finalize
+// returns it to the mode ao_net_set_mode asked for) or ao_net_set_mode is called again.
+void net_fp16_fallback_begin(ao_net* n) {
+    ++n->fp16_fallbacks;
+    n->mode = 2;
+}
+int net_fp16_fallback_end(ao_net* n) {
+    n->forced_fp32 = n->fp16_fallbacks >= 3;
+    if (!n->forced_fp32) n->mode = n->requested_mode;
+    return n->forced_fp32 ? 1 : 0;
+}
+}  // namespace ao
+
 extern "C" {
 
 const char* ao_net_last_error(const ao_net* n) { return n ? n->err.c_str() : g_net_create_error.c_str(); }
@@ -713,21 +729,6 @@ int ao_net_set_mode(ao_net* n, int mode) {
     return 0;
 }
 
-namespace ao {
-// The engine's fp16-range recovery (ao_search): the move is repeated on the fp32-MFMA trunk (mode 2). The fallback
-// belongs to the WEIGHTS that overflowed: it is counted per network object since its last ao_net_finalize; from the
-// third repeated move on the network stays on the fp32-MFMA trunk -- until new weights are loaded (ao_net_finalize
-// returns it to the mode ao_net_set_mode asked for) or ao_net_set_mode is called again.
-void net_fp16_fallback_begin(ao_net* n) {
-    ++n->fp16_fallbacks;
-    n->mode = 2;
-}
-int net_fp16_fallback_end(ao_net* n) {
-    n->forced_fp32 = n->fp16_fallbacks >= 3;
-    if (!n->forced_fp32) n->mode = n->requested_mode;
-    return n->forced_fp32 ? 1 : 0;
-}
-}  // namespace ao
 
 int ao_net_get_mode(const ao_net* n) { return n->mode; }
 
