@@ -76,6 +76,9 @@ STRICT = False               # configure(strict=True): an arena trim raises Tree
 NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 16*(sims+1) within 30 % of the HBM; -1: grow into the free HBM)
 last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of every search of the last _play_episodes call
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
+# search shape, cumulative since configure(): PUCT levels walked, exact-tie draws, terminal leaves, evaluated leaves over all
+# simulations of all searches (levels / (evaluated + terminal) = mean selection depth)
+search_totals = {'levels': 0, 'ties': 0, 'terminal': 0, 'evaluated': 0, 'searches': 0}
 CARRY_OVER = False           # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
 CARRY_CALLS = 2              # ... of at most this many calls ahead
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
@@ -105,6 +108,8 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     NODE_CAP = NODE_CAP if node_cap is None else int(node_cap)
     _trim_base[0] = _trim_base[1] = 0
     trim_stats['subtrees_dropped'] = trim_stats['reroots_trimmed'] = 0
+    for k in search_totals:
+        search_totals[k] = 0
     import torch
     from .pvnet import PVNet
     BOARD_SIZE = board_size or BOARD_SIZE
@@ -170,6 +175,14 @@ class TreeTrimmed(RuntimeError):
     dict never forgets, agents.py:52), so the searches of those games no longer follow the reference."""
 
 
+def _count_search(eng):
+    """Adds the last search's shape counters (ao_search_stats: per move, summed over its games) to search_totals."""
+    st = eng.search_stats()
+    for k in ('levels', 'ties', 'terminal', 'evaluated'):
+        search_totals[k] += st[k]
+    search_totals['searches'] += 1
+
+
 def _check_trim(eng):
     dropped, trimmed = eng.trim_stats()
     trim_stats['subtrees_dropped'] = _trim_base[0] + dropped
@@ -217,6 +230,7 @@ def _play_episodes(episodes, use_global, seed_of):
         tau = (ply < TAU_THRES).astype(np.int8)           # main.py:150-153
         t_search = time.perf_counter()
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
+        _count_search(eng)
         act, win = eng.play()                             # utils.get_action + env.step
         if trace is not None:
             trace.append((int(active.sum()), time.perf_counter() - t_search))
@@ -336,6 +350,7 @@ def _play_carry(first_episode, n_call, rank, world):
         tau = (pool.ply < TAU_THRES).astype(np.int8)      # main.py:150-153
         t_search = time.perf_counter()
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=pool.active)
+        _count_search(eng)
         act, win = eng.play()
         if trace is not None:
             trace.append((int(pool.active.sum()), time.perf_counter() - t_search))

@@ -361,6 +361,85 @@ class TrainStep:
         return r
 
 
+TRAINED_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_trained_9x9_4block.pt")
+
+
+def trained_net_bench(args, local, path, steps=8, warm_plies=8):
+    """The headline workload with a TRAINED network (a checkpoint of tools/train_omok.py: this engine's own self-play +
+    main.train on the MI355X) instead of random-init weights: sharp priors, so the searches go deep, meet terminal leaves
+    and keep most of the tree from move to move -- the regime the tree kernels exist for. Fresh engine, `warm_plies`
+    untimed move decisions (the tau switch at ply 6 included), then `steps` timed ones with refills."""
+    from alpha_omok_amd.engine import Engine
+    from alpha_omok_amd.pvnet import PVNet
+    B, S, G = args.board, args.sims, args.games
+    model = PVNet(args.blocks, 5, args.planes, B)
+    model.load_state_dict(torch.load(path, map_location="cpu"))
+    model.eval()
+    net = model.to_native(local)
+    eng = Engine(B, S, 5, games=G, noise=True, device=local)
+    eng.seed_all(np.arange(7 * G, 8 * G, dtype=np.uint32))
+    ply = np.zeros(G, np.int64)
+    nxt = [9 * G]
+    c = dict(levels=0, evaluated=0, terminal=0, games=0)
+
+    def one(count):
+        eng.search(net, tau=(ply < 6).astype(np.int8))
+        st = eng.search_stats()
+        act, win = eng.play()
+        ply[:] += 1
+        done = win != 0
+        if count:
+            for k in ("levels", "evaluated", "terminal"):
+                c[k] += st[k]
+            c["games"] += int(done.sum())
+        if done.any():
+            eng.reset(done.astype(np.uint8))
+            for g in np.nonzero(done)[0]:
+                eng.seed(int(g), nxt[0])
+                nxt[0] += 1
+            ply[done] = 0
+
+    for _ in range(warm_plies):
+        one(False)
+    eng.tree_timing(True)
+    net.conv_timing(True)
+    eng.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(True)
+    eng.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n = net.conv_timing(False)
+    tree_ms, tree_n = eng.tree_timing(False)
+    sims_total = max(c["evaluated"] + c["terminal"], 1)
+    d_bar = c["levels"] / sims_total
+    A_ = B * B
+    tree_bytes = G * (A_ * (16.0 * d_bar + 44.0) + 24.0 * (d_bar + 1.0) + 4.0)   # SURVEY.md 8(d), C = 5
+    tree_avg = tree_ms / max(tree_n, 1)
+    dropped, trimmed = eng.trim_stats()
+    ev, evg = eng.fp16_range_events()
+    kname, f_launch = net.dominant_kernel(G)
+    r = {"weights": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))),
+         "workload": "same games / sims / slots as the headline, network = the committed checkpoint trained by this engine "
+                     "(tools/train_omok.py); plies %d-%d timed" % (warm_plies, warm_plies + steps - 1),
+         "value": G * steps / dt, "unit": "move-decisions/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+         "mean_select_depth": d_bar, "terminal_leaf_fraction": c["terminal"] / sims_total, "games_finished": c["games"],
+         "trunk_kernel": kname.split(" (")[0], "trunk_avg_launch_ms": conv_ms / max(conv_n, 1),
+         "trunk_time_share": conv_ms * 1e-3 / dt,
+         "roofline_tree": {"kernel": "k_expand_select", "avg_launch_ms": tree_avg, "launches_timed": tree_n,
+                           "algorithmic_bytes_per_launch": tree_bytes,
+                           "achieved": tree_bytes / (tree_avg * 1e-3) / 1e9 if tree_n else 0.0, "unit": "GB/s", "peak": 8000.0,
+                           "frac": tree_bytes / (tree_avg * 1e-3) / 1e9 / 8000.0 if tree_n else 0.0,
+                           "time_share": tree_ms * 1e-3 / dt},
+         "node_cap": eng.node_cap()[0], "arena_trims": {"subtrees_dropped": dropped, "reroots_trimmed": trimmed},
+         "fp16_range_events": ev}
+    eng.close()
+    net.close()
+    return r
+
+
 def launch_ranks(n):
     """Re-run this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1). Fails loudly -- exit code
     2, nothing printed on stdout -- when fewer than n GPUs are visible, instead of reporting a 1-GPU number under an
@@ -411,6 +490,8 @@ def main():
     ap.add_argument("--prefill-games", type=int, default=48, help="self-play games per GPU that fill the replay shard (untimed)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-hardware-thread CPU sample")
     ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0, help="seconds per process of the all-cores sample")
+    ap.add_argument("--trained-weights", default=TRAINED_CKPT, help="state_dict of a trained 9x9 / 4-block / 128-plane PVNet for the `trained_net` leg")
+    ap.add_argument("--no-trained-net", action="store_true", help="skip the `trained_net` leg (the headline workload with trained weights)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -659,6 +740,11 @@ def main():
                 net10.close()
             except Exception as e:
                 out["ten_block_net"] = {"value": None, "error": repr(e)}
+        if world == 1 and not args.no_trained_net and os.path.exists(args.trained_weights) and (B, args.blocks, args.planes) == (9, 4, 128):
+            try:
+                out["trained_net"] = trained_net_bench(args, local, args.trained_weights)
+            except Exception as e:
+                out["trained_net"] = {"value": None, "error": repr(e)}
         if world == 1 and G > 1 and not args.no_single_game:
             # BASELINE configs[1] beside the headline: ONE game, 400 sims/move, same network
             # (latency path: per-board conv kernels, no concurrency to hide behind)

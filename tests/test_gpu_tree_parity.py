@@ -1,6 +1,8 @@
 """-m gpu: the HIP tree kernels (through the C ABI) against the CPU oracle and against the golden
 vectors captured from the reference. Bar: bit-exact visit counts, priors, w/q, chosen moves and
 MT19937 stream position (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -399,4 +401,102 @@ def test_full_size_properties_and_sampled_oracle_parity(oracle, B, S, G, blocks)
     np.testing.assert_array_equal(pol2, first_pol)
     eng.close()
     eng2.close()
+    net.close()
+
+
+def test_trained_network_deep_trees_and_sampled_oracle_parity(oracle):
+    """The regime a TRAINED network puts the tree kernels in, at G = 1024: sharp priors, so the PUCT descents go 6 - 25
+    levels deep, meet terminal leaves inside the batch, and the played child keeps most of the root's visits (inherited
+    counts of several times S; the arena default must hold them without a trim). Network: tests/golden/trained_2block_9x9.npz
+    -- trained by THIS engine on the MI355X (tools/train_omok.py, tools/exp/r4a.sh: 113 k self-play games, 64 : 0 against
+    its iteration 0; tools/make_trained_fixture.py made the fixture). Fourteen plies with re-rooting, tau = 1 for six plies
+    then 0 (main.py:150-153); five sampled games are replayed through the oracle at every ply with the recorded (p, v):
+    visits, post-noise priors, pi, action, MT19937 position and state bit for bit; games that end stay ended."""
+    import sys
+    import torch
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from make_trained_fixture import load
+    from alpha_omok_amd.engine import Engine, Net
+    B, S, G, PLIES = 9, 400, 1024, 14
+    A = B * B
+    sd = load(os.path.join(REPO, "tests", "golden", "trained_2block_9x9.npz"))
+    net = Net(2, 5, 128, B, 0)
+    net.load_state_dict(sd)
+    eng = Engine(B, S, 5, games=G, noise=True)
+    seeds = np.arange(31000, 31000 + G, dtype=np.uint32)
+    eng.seed_all(seeds)
+    sample = [0, 1, 17, G // 2, G - 1]
+    planes = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
+    cursors = {g: [0] for g in sample}
+    recs = {g: [] for g in sample}
+
+    def make_agent(g, seed):
+        def replay(moves, pl, sim, g=g):
+            i = cursors[g][0]
+            cursors[g][0] += 1
+            return recs[g][i]
+        ag = oracle.Agent(B, S, 5, noise=True, evaluator=replay)
+        ag.seed(int(seed))
+        return ag
+
+    agents = {g: make_agent(g, seeds[g]) for g in sample}
+    roots = {g: (0,) for g in sample}
+    alive = np.ones(G, np.uint8)
+    inherited = np.zeros(G)
+    depth, terminal_total, max_inherited, checked = [], 0, 0.0, 0
+    for t in range(PLIES):
+        tau = np.full(G, 1 if t < 6 else 0, np.int8)
+        for g in sample:
+            recs[g] = []
+            cursors[g][0] = 0
+        eng.begin_move(alive)
+        while eng.sims_left() > 0:
+            eng.collect_leaves(planes.data_ptr())
+            eng.sync()
+            p, v = net(planes)                       # ao_net_forward: the kernels ao_search uses
+            torch.cuda.synchronize()
+            hp, hv = p[sample].cpu().numpy(), v[sample].cpu().numpy()
+            for i, g in enumerate(sample):
+                recs[g].append((hp[i].copy(), hv[i].copy()))
+            eng.apply_evals(p.data_ptr(), v.data_ptr())
+        pi, vis, pol = eng.end_move(tau)
+        on = alive != 0
+        st = eng.search_stats()
+        n_sims = int(on.sum()) * S + (int(on.sum()) if t == 0 else 0)
+        assert st["evaluated"] + st["terminal"] == n_sims
+        depth.append(st["levels"] / n_sims)
+        terminal_total += st["terminal"]
+        max_inherited = max(max_inherited, float(inherited[on].max()))
+        np.testing.assert_array_equal(vis[on].sum(axis=1), inherited[on] + S)
+        assert np.abs(pi[on].sum(axis=1) - 1).max() < 1e-12 and np.abs(pol[on].sum(axis=1) - 1).max() < 1e-9
+        act, win = eng.play()
+        assert np.all(vis[on, act[on]] > 0)
+        for g in sample:
+            if not alive[g]:
+                continue
+            tag = "game %d ply %d" % (g, t)
+            opi, ovis, opol = agents[g].get_pi(roots[g], int(tau[g]))
+            np.testing.assert_array_equal(vis[g], ovis, err_msg=tag)
+            np.testing.assert_array_equal(pol[g], opol, err_msg=tag)
+            np.testing.assert_array_equal(pi[g], opi, err_msg=tag)
+            oa = agents[g].rng.choice_p(opi)
+            assert act[g] == oa, tag
+            roots[g] = roots[g] + (int(oa),)
+            mt, pos, _, _ = eng.get_rng_state(g)
+            assert pos == agents[g].rng.pos, tag
+            np.testing.assert_array_equal(mt, agents[g].rng.state_words(), err_msg="mt " + tag)
+            assert win[g] == oracle.check_win(oracle.get_board(list(roots[g][1:]), B), 5), tag
+            checked += 1
+        inherited = np.where(on, vis[np.arange(G), act] - 1, 0.0)
+        alive[on & (win != 0)] = 0
+        if not alive.any():
+            break
+    # the regime was the one the test is for
+    assert max(depth) >= 6.0, depth
+    assert terminal_total > 0
+    assert max_inherited >= 2 * S, max_inherited
+    assert checked >= 3 * 10, checked                         # >= 3 sampled games alive through >= 10 plies
+    assert eng.trim_stats() == (0, 0) and eng.node_cap()[0] >= 8 * (S + 1)
+    eng.close()
     net.close()

@@ -290,3 +290,40 @@ def test_gv13_mixed_matches_rollout_player_with_monitor(oracle):
             assert shared.pos == int(g["m%d_mt_pos" % mi][t]), (mi, t)
             root = root + (int(mv),)
         assert oracle.check_win(oracle.get_board(list(root)[1:], B), 5) == int(g["m%d_win" % mi])
+
+
+def test_trained_fixture_loads_and_makes_the_oracle_search_deep(oracle):
+    """tests/golden/trained_2block_9x9.npz (a network trained by the engine itself, tools/make_trained_fixture.py): the
+    state_dict wire format loads into PVNet, and under the ORACLE's sequential search its sharp priors give the deep,
+    terminal-hitting descents the GPU test of the same name relies on (random-init networks stay at depth ~1.9)."""
+    import os
+    import sys
+    import torch
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from make_trained_fixture import load
+    from alpha_omok_amd.pvnet import PVNet
+    sd = load(os.path.join(REPO, "tests", "golden", "trained_2block_9x9.npz"))
+    net = PVNet(2, 5, 128, 9)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net.eval()
+    torch.set_num_threads(2)
+
+    def ev(moves, planes, sim):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(np.array(planes, np.float32))[None])
+        return p[0].numpy(), float(v[0])
+
+    S = 100
+    ag = oracle.Agent(9, S, 5, noise=True, evaluator=ev)
+    ag.seed(123)
+    root, depths = (0,), []
+    for ply in range(8):
+        pi, vis, pol = ag.get_pi(root, 1 if ply < 6 else 0)
+        assert vis.sum() >= S and abs(pi.sum() - 1) < 1e-12
+        depths.append(ag.last_stats()["levels"] / (S + (ply == 0)))
+        root = root + (int(ag.rng.choice_p(pi)),)
+        if oracle.check_win(oracle.get_board(list(root[1:]), 9), 5):
+            break
+    assert pol.max() > 0.3                                   # a sharp prior at the root (random init: ~1 / 81 + noise)
+    assert max(depths) >= 4.0, depths

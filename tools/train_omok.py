@@ -77,7 +77,8 @@ def main():
     kept = []
     t_end = time.time() + 60.0 * a.minutes
     games_total = moves_total = 0
-    prev = dict(levels=0, ties=0, terminal=0, evaluated=0)
+    prev = dict(m.search_totals)
+    prev_model, prev_iter, chain = None, 0, 0.0
     it = 0
     while it < a.iters and time.time() < t_end:
         n = a.games if (it > 0 or a.first_games is None) else a.first_games
@@ -85,11 +86,8 @@ def main():
         out = m.self_play(n)
         t_sp = time.time() - t0
         eng = m._engine
-        st = eng.search_stats()
-        d = {k: st[k] - prev[k] for k in st}
-        if any(v < 0 for v in d.values()):               # (a rebuilt engine starts its counters at zero)
-            d = dict(st)
-        prev = dict(st)
+        d = {k: m.search_totals[k] - prev[k] for k in prev}   # this call's searches (main.search_totals is cumulative)
+        prev = dict(m.search_totals)
         lengths = out["moves"] / max(out["episodes"], 1)
         res = dict(m.result)
         t0 = time.time()
@@ -126,6 +124,24 @@ def main():
                       player_elo=round(pe, 1), enemy_elo=round(ee, 1), elo_gain_reference_K32=round(pe - 1500.0, 1),
                       score=round(score, 4), elo_diff_from_score=round(float(ml), 1),
                       mean_plies=round(float(np.mean([len(g[1]) for g in games])), 1), eval_s=round(time.time() - t0, 2)))
+            # ... and against the network of the previous evaluation point: the chain of these differences keeps measuring
+            # progress after "beats iteration 0 every time" has saturated
+            if prev_model is not None:
+                t0 = time.time()
+                result, (pe, ee), games = evaluate.evaluate_batched(m.Agent.model, prev_model, a.board, a.eval_sims or a.sims,
+                                                                    n_match=a.eval_matches, seed=5000 + it, device=0)
+                w, l, dr = result["Player"], result["Enemy"], result["Draw"]
+                score = (w + 0.5 * dr) / max(w + l + dr, 1)
+                ml = 400.0 * np.log10(max(score, 0.01) / max(1 - score, 0.01))
+                chain += float(ml)
+                emit(dict(kind="elo", iter=it, vs="iter%d" % prev_iter, matches=a.eval_matches, result=result,
+                          elo_gain_reference_K32=round(pe - 1500.0, 1), score=round(score, 4),
+                          elo_diff_from_score=round(float(ml), 1), chain_elo_from_scores=round(chain, 1),
+                          mean_plies=round(float(np.mean([len(g[1]) for g in games])), 1), eval_s=round(time.time() - t0, 2)))
+            prev_model = PVNet(a.blocks, m.IN_PLANES, a.planes, a.board).to(dev)
+            prev_model.load_state_dict(m.Agent.model.state_dict())
+            prev_model.eval()
+            prev_iter = it
         if it % a.ckpt_every == 0:
             path = os.path.join(a.out, "ckpt_%d.pt" % it)
             torch.save(m.Agent.model.state_dict(), path)
