@@ -178,6 +178,49 @@ def test_full_size_batch_all_paths_agree():
     net.close()
 
 
+@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 1024, 321), (4, 9, 1000, 77), (2, 9, 390, 5), (10, 9, 512, 9), (3, 7, 640, 12),
+                                             (2, 5, 1024, 3), (1, 4, 700, 8), (2, 8, 777, 6), (2, 6, 512, 4)])
+def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
+    """Medium batches (24 .. 64 groups of 16 boards, boards up to 9x9) run their trunk convs as k_layer16hk: a group split
+    over four workgroups by cout pairs, the eight waves of a workgroup splitting the contraction by input block, partial
+    tiles exchanged through LDS (net_layer_ksplit.hpp). Checked against the per-layer kernel it replaces (mode 6), the
+    fp32-MFMA kernels (mode 4: no fp16 anywhere) and torch fp32; twice, bit-identical (the exchange adds in a fixed order);
+    ragged last group (batch not a multiple of 16), residual and non-residual layers, in-place second conv of a block."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    sd = pvnet_weights.make_state_dict(nb, 5, 128, B, seed)
+    ref = PVNet(nb, 5, 128, B)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ref.eval()
+    rs = np.random.RandomState(batch + B)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    x[:, 4] = (rs.rand(batch, 1, 1) < 0.5).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    net = ref.to_native(0)
+    outs = {}
+    for mode in (5, 6, 4, 5):
+        net.set_mode(mode)
+        p, v = net(xt)
+        torch.cuda.synchronize()
+        if mode == 5:
+            assert net.dominant_kernel(batch)[0].startswith("k_layer16hk<%d>" % B), net.dominant_kernel(batch)[0]
+        p, v = p.cpu().numpy(), v.cpu().numpy()
+        assert np.isfinite(p).all() and np.isfinite(v).all() and net.status() == 0
+        if mode in outs:
+            np.testing.assert_array_equal(outs[mode][0], p)
+            np.testing.assert_array_equal(outs[mode][1], v)
+        outs[mode] = (p, v)
+    for m in (6, 4):
+        assert np.abs(outs[5][0] - outs[m][0]).max() < 2e-5, m
+        assert np.abs(outs[5][1] - outs[m][1]).max() < 2e-5, m
+    idx = rs.choice(batch, 128, replace=False)
+    idx[:4] = [0, 15, batch - 1, batch - (batch % 16 or 16)]        # first group, last (ragged) group
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x[idx]))
+    assert np.abs(outs[5][0][idx] - rp.numpy()).max() < TOL and np.abs(outs[5][1][idx] - rv.numpy()).max() < TOL
+    net.close()
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("nb,B,seed", [(4, 9, 77), (10, 9, 5), (6, 7, 12), (1, 5, 3)])
 def test_resident_trunk_both_activation_formats(nb, B, seed, fmt, monkeypatch):
