@@ -76,7 +76,7 @@ struct ao_net {
     double ms_total = 0.0;
     int64_t launches = 0;
     int last_in_kind = 1;                          // input of the most recent forward: 1 fp32 plane batch, 2 the engine's bit planes
-    int trunk_fmt = -1;                            // activation format inside the resident split-fp16 trunk (kPairBytes): -1 = by depth (3 bytes up to 6 ResBlocks, else 4), 0 / 1 forced (AO_TRUNK_FMT)
+    int trunk_fmt = -1;                            // activation format inside the resident split-fp16 trunk (kPairBytes): 0 = two fp16 halves (default), 1 = fp16 high half + one low byte (AO_TRUNK_FMT=1)
 
     int fail(const std::string& m) { err = m; return 1; }
 };
@@ -740,9 +740,11 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
         if (sscanf(v, "%d,%d", &lo, &hi) == 2) { n->ksplit_min = lo > 0 ? lo : 1 << 30; n->ksplit_max = hi; }
     }
     if (const char* v = getenv("AO_TRUNK_FMT")) n->trunk_fmt = atoi(v) == 1 ? 1 : 0;
-    // 19-bit activations cost ~8 x the rounding error of the two-half format (profiles/r3a_*): measured against fp64 on the
-    // golden-vector networks 1.8e-5 at 4 blocks, 3.5e-5 at 10 -- the deeper networks keep the 4-byte format
-    if (n->trunk_fmt < 0) n->trunk_fmt = n_block <= 6 ? 1 : 0;
+    // Default: two fp16 halves (4 bytes, ~22 significand bits). The 3-byte format (19 bits) is 2 % faster and costs ~4-8 x the
+    // rounding error: on a TRAINED 4-block network (profiles/r4_trained_net_check.json, 4096 real self-play positions) 2.8e-5 on
+    // the policy against torch fp32 where the 4-byte format has 7.8e-6 -- inside the 1e-4 bar, but 3.5 x instead of 13 x away
+    // from it, for a gain below the box-to-box spread. It stays available as AO_TRUNK_FMT=1.
+    if (n->trunk_fmt < 0) n->trunk_fmt = 0;
     if (const char* v = getenv("AO_XT")) n->force_xt = atoi(v) == 4 ? 4 : (atoi(v) == 5 ? 5 : 0);
     if (const char* v = getenv("AO_NCH")) n->force_nch = atoi(v) > 0 && atoi(v) <= board ? atoi(v) : 0;
     *out = n;
@@ -1123,7 +1125,7 @@ int ao_net_plan_kernel(int n_block, int inplanes, int planes, int board, int tru
     n.CQ = planes / 4;
     n.mode = trunk_mode;
     if (const char* v = getenv("AO_TRUNK_FMT")) n.trunk_fmt = atoi(v) == 1 ? 1 : 0;
-    if (n.trunk_fmt < 0) n.trunk_fmt = n_block <= 6 ? 1 : 0;   // as ao_net_create
+    if (n.trunk_fmt < 0) n.trunk_fmt = 0;   // as ao_net_create
     std::string nm;
     double f = 0.0;
     dominant_name(&n, boards, in_kind, &nm, &f);

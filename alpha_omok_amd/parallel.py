@@ -98,18 +98,12 @@ def agree_sums(values, device=None):
     vals = [int(v) for v in values]
     if not _collectives_on() or not vals:
         return vals
-    t = torch.tensor(vals, dtype=torch.int64, device=device or "cpu")
-    if dist.get_backend() == "nccl" and not t.is_cuda:
-        t = t.cuda()
-    dist.all_reduce(_staged_inplace(t), op=dist.ReduceOp.SUM)
+    # (host tensor under gloo -- two test ranks may share one GPU --, device tensor under nccl = RCCL)
+    t = torch.tensor(vals, dtype=torch.int64, device="cpu")
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None and torch.device(device).type == "cuda" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.cpu().tolist()]
-
-
-def _staged_inplace(t):
-    """`t` itself where the backend can reduce it in place (nccl on device memory, gloo on host memory)."""
-    import torch.distributed as dist
-    assert not (dist.get_backend() == "gloo" and t.is_cuda)
-    return t
 
 
 def allreduce_gradients(module, contributes=True, weight=1.0, total=None):

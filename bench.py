@@ -633,7 +633,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (fp16x2-split MFMA operands, 3 products per multiply-add, f32 accumulate)" if split16 else "f32",
+            # the arithmetic type AND, for the resident split-fp16 trunk, the precision its activations are STORED with between
+            # layers (kPairBytes: two fp16 halves = ~22 significand bits, or fp16 high half + one low byte = 19)
+            "dtype": ("f32 (fp16x2-split MFMA operands, 3 products per multiply-add, f32 accumulate; inter-layer activations stored as "
+                      + ("fp16 high half + 8 low bits: 19 significand bits)" if kname.startswith("k_trunk16h") and ", 1> (" in kname
+                         else "two fp16 halves: ~22 significand bits)")) if split16 else "f32",
             "data": "synthetic (self-play from the empty board, random-init weights, per-game seeds)",
             "config": {
                 "workload": "%s: %dx%d Omok, %d concurrent self-play games per GPU, %d sims/move, "

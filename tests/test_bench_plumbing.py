@@ -45,7 +45,7 @@ def test_kernel_key_normalises_rocprof_and_library_names():
 
 def test_plan_kernel_follows_batch_size_and_input_kind():
     from alpha_omok_amd.engine import plan_kernel
-    assert plan_kernel(4, 5, 128, 9, 4096, in_kind=1)[0].startswith("k_trunk16h<9, 4, 1>")
+    assert plan_kernel(4, 5, 128, 9, 4096, in_kind=1)[0].startswith("k_trunk16h<9, 4, 0>")
     assert plan_kernel(10, 5, 128, 9, 4096, in_kind=2)[0].startswith("k_trunk16hb<9, 4, 0>")
     assert plan_kernel(4, 5, 128, 9, 1, in_kind=1)[0].startswith("k_conv_cells_h<9, 8>")
     assert plan_kernel(4, 5, 64, 9, 1, in_kind=1)[0].startswith("k_conv_cells<9>")

@@ -225,9 +225,9 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
 @pytest.mark.parametrize("nb,B,seed", [(4, 9, 77), (10, 9, 5), (6, 7, 12), (1, 5, 3)])
 def test_resident_trunk_both_activation_formats(nb, B, seed, fmt, monkeypatch):
     """The resident split-fp16 trunk keeps its activations between layers as two fp16 halves (4 bytes, AO_TRUNK_FMT=0) or as
-    an fp16 high half + one low byte (3 bytes, 19 significand bits, AO_TRUNK_FMT=1; the default up to 6 ResBlocks): both
-    against the torch fp32 network on golden-vector weights at 3072 boards (192 groups: the resident kernel), and the
-    format the library picks by depth."""
+    an fp16 high half + one low byte (3 bytes, 19 significand bits, AO_TRUNK_FMT=1, opt-in since round 4): both against the
+    torch fp32 network on golden-vector weights at 3072 boards (192 groups: the resident kernel); the default is the 4-byte
+    format at every depth."""
     import torch
     from alpha_omok_amd.pvnet import PVNet
     batch = 3072
@@ -252,7 +252,7 @@ def test_resident_trunk_both_activation_formats(nb, B, seed, fmt, monkeypatch):
     net.close()
     auto = ref.to_native(0)
     auto.set_mode(5)
-    assert auto.dominant_kernel(batch)[0].startswith("k_trunk16h<%d, 4, %d>" % (B, 1 if nb <= 6 else 0))
+    assert auto.dominant_kernel(batch)[0].startswith("k_trunk16h<%d, 4, 0>" % B)
     auto.close()
 
 

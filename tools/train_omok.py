@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--eval-every", type=int, default=5)
     ap.add_argument("--eval-matches", type=int, default=64)
     ap.add_argument("--eval-sims", type=int, default=None)
+    ap.add_argument("--yardstick", default=None, help="'puct:400' / 'uct:400': also play every evaluation against the rollout agent "
+                                                      "(agents.py:263-634) with that many simulations -- a fixed opponent that needs no network")
+    ap.add_argument("--eval-dense-until", type=int, default=0, help="evaluate after EVERY iteration up to this one (the steep part of the curve)")
     ap.add_argument("--ckpt-every", type=int, default=10)
     ap.add_argument("--max-ckpts", type=int, default=6, help="checkpoints kept on disk besides iteration 0 and final (gpurun_out is merged back up to 64 MiB)")
     ap.add_argument("--seed", type=int, default=0)
@@ -74,6 +77,14 @@ def main():
     torch.save(base.state_dict(), os.path.join(a.out, "ckpt_0.pt"))
     emit(dict(kind="config", **vars(a), device=torch.cuda.get_device_name(0)))
 
+    if a.yardstick:                                       # where the untrained network stands against the fixed opponent
+        kind, ysims = a.yardstick.split(":")
+        t0 = time.time()
+        yr, (ype, yee), yg = evaluate.evaluate_batched(base, kind, a.board, a.eval_sims or a.sims, n_mcts_enemy=int(ysims),
+                                                       n_match=a.eval_matches, seed=9000, device=0)
+        emit(dict(kind="elo", iter=0, vs=a.yardstick, matches=a.eval_matches, result=yr, elo_gain_reference_K32=round(ype - 1500.0, 1),
+                  score=round((yr["Player"] + 0.5 * yr["Draw"]) / max(sum(yr.values()), 1), 4),
+                  mean_plies=round(float(np.mean([len(g[1]) for g in yg])), 1), eval_s=round(time.time() - t0, 2)))
     kept = []
     t_end = time.time() + 60.0 * a.minutes
     games_total = moves_total = 0
@@ -112,9 +123,17 @@ def main():
         emit(rec)
         m.reset_iter(m.result, m.cur_memory)
         it += 1
-        if it % a.eval_every == 0:
+        if it % a.eval_every == 0 or it <= a.eval_dense_until:
             t0 = time.time()
             m.Agent.model.eval()
+            if a.yardstick:
+                kind, ysims = a.yardstick.split(":")
+                yr, (ype, yee), yg = evaluate.evaluate_batched(m.Agent.model, kind, a.board, a.eval_sims or a.sims, n_mcts_enemy=int(ysims),
+                                                               n_match=a.eval_matches, seed=9000 + it, device=0)
+                ysc = (yr["Player"] + 0.5 * yr["Draw"]) / max(sum(yr.values()), 1)
+                emit(dict(kind="elo", iter=it, vs=a.yardstick, matches=a.eval_matches, result=yr, elo_gain_reference_K32=round(ype - 1500.0, 1),
+                          score=round(ysc, 4), mean_plies=round(float(np.mean([len(g[1]) for g in yg])), 1), eval_s=round(time.time() - t0, 2)))
+                t0 = time.time()
             result, (pe, ee), games = evaluate.evaluate_batched(m.Agent.model, base, a.board, a.eval_sims or a.sims,
                                                                 n_match=a.eval_matches, seed=1000 + it, device=0)
             w, l, dr = result["Player"], result["Enemy"], result["Draw"]
@@ -126,7 +145,7 @@ def main():
                       mean_plies=round(float(np.mean([len(g[1]) for g in games])), 1), eval_s=round(time.time() - t0, 2)))
             # ... and against the network of the previous evaluation point: the chain of these differences keeps measuring
             # progress after "beats iteration 0 every time" has saturated
-            if prev_model is not None:
+            if prev_model is not None and it % a.eval_every == 0:
                 t0 = time.time()
                 result, (pe, ee), games = evaluate.evaluate_batched(m.Agent.model, prev_model, a.board, a.eval_sims or a.sims,
                                                                     n_match=a.eval_matches, seed=5000 + it, device=0)
@@ -138,10 +157,11 @@ def main():
                           elo_gain_reference_K32=round(pe - 1500.0, 1), score=round(score, 4),
                           elo_diff_from_score=round(float(ml), 1), chain_elo_from_scores=round(chain, 1),
                           mean_plies=round(float(np.mean([len(g[1]) for g in games])), 1), eval_s=round(time.time() - t0, 2)))
-            prev_model = PVNet(a.blocks, m.IN_PLANES, a.planes, a.board).to(dev)
-            prev_model.load_state_dict(m.Agent.model.state_dict())
-            prev_model.eval()
-            prev_iter = it
+            if it % a.eval_every == 0:
+                prev_model = PVNet(a.blocks, m.IN_PLANES, a.planes, a.board).to(dev)
+                prev_model.load_state_dict(m.Agent.model.state_dict())
+                prev_model.eval()
+                prev_iter = it
         if it % a.ckpt_every == 0:
             path = os.path.join(a.out, "ckpt_%d.pt" % it)
             torch.save(m.Agent.model.state_dict(), path)
