@@ -66,7 +66,9 @@ struct ao_net {
     float *tmp_p = nullptr, *tmp_v = nullptr;
     int* d_status = nullptr;                       // bit 0: an activation left the fp16 range in the split-fp16 trunk
     bool attr_l[16][2] = {}, attr_done[16] = {}, lds_attr_done[16] = {}, attr_k[16] = {};
-    int ksplit_min = 24, ksplit_max = 64;         // groups for which the trunk convs of the per-layer path run as k_layer16hk (AO_KSPLIT=lo,hi; 0,0 = off)
+    // groups for which the trunk convs of the per-layer path run as k_layer16hk: [ksplit_min, ksplit_max] with four workgroups per
+    // group (KS = 4), (ksplit_max, ksplit_max2] with two (KS = 2). AO_KSPLIT=lo,hi4,hi2 overrides (0,0,0 = off)
+    int ksplit_min = 56, ksplit_max = 64, ksplit_max2 = 128;
     int force_xt = 0, force_nch = 0;               // AO_XT / AO_NCH: tiling overrides for timing experiments (read at create)  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
     bool timing = false;
@@ -459,7 +461,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         // medium batches of boards up to 9x9: the trunk convs split a group by cout pairs over four workgroups whose
         // waves split the contraction (net_layer_ksplit.hpp); conv1 stays with k_layer16h. Never in mode 6 (one
         // arithmetic for every batch size).
-        const bool ksplit = !layers_only(n) && n->B >= 4 && n->B <= 9 && groups >= n->ksplit_min && groups <= n->ksplit_max;
+        const int ks = (!layers_only(n) && n->B >= 4 && n->B <= 9 && groups >= n->ksplit_min) ? (groups <= n->ksplit_max ? 4 : groups <= n->ksplit_max2 ? 2 : 0) : 0;
+        const bool ksplit = ks != 0;
         auto layer_k = [&](int l) -> int {
             LayerHArgs a;
             a.src = static_cast<const void*>((l & 1) ? n->act_x : n->act_t);
@@ -471,18 +474,21 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.ovf = n->d_status;
             a.res = !(l & 1) ? 1 : 0;
             a.nch = groups;
-            const dim3 grid((groups + 7) / 8 * 8 * 4), block(512);
+            const dim3 grid((groups + 7) / 8 * 8 * ks), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
             switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W: {                                                                                                          \
         constexpr size_t lds_ = static_cast<size_t>(2) * W * 8 * 1024;                                                 \
         if (!n->attr_k[W]) {                                                                                           \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16hk<W>),                             \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16hk<W, 4>),                          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_layer16hk<W, 2>),                          \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
             n->attr_k[W] = true;                                                                                       \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_layer16hk<W>), grid, block, lds_, s, a);                                                 \
+        if (ks == 4) hipLaunchKernelGGL((k_layer16hk<W, 4>), grid, block, lds_, s, a);                                 \
+        else hipLaunchKernelGGL((k_layer16hk<W, 2>), grid, block, lds_, s, a);                                         \
     } break;
                 AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
 #undef AO_BW_CASE
@@ -735,9 +741,9 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             n->num_cu = prop.multiProcessorCount;
     }
-    if (const char* v = getenv("AO_KSPLIT")) {   // "lo,hi": groups that take k_layer16hk (timing experiments; "0,0" turns it off)
-        int lo = 0, hi = 0;
-        if (sscanf(v, "%d,%d", &lo, &hi) == 2) { n->ksplit_min = lo > 0 ? lo : 1 << 30; n->ksplit_max = hi; }
+    if (const char* v = getenv("AO_KSPLIT")) {   // "lo,hi4,hi2": groups that take k_layer16hk (timing experiments; "0,0,0" turns it off)
+        int lo = 0, hi = 0, hi2 = 0;
+        if (sscanf(v, "%d,%d,%d", &lo, &hi, &hi2) == 3) { n->ksplit_min = lo > 0 ? lo : 1 << 30; n->ksplit_max = hi; n->ksplit_max2 = hi2; }
     }
     if (const char* v = getenv("AO_TRUNK_FMT")) n->trunk_fmt = atoi(v) == 1 ? 1 : 0;
     // Default: two fp16 halves (4 bytes, ~22 significand bits). The 3-byte format (19 bits) is 2 % faster and costs ~4-8 x the
@@ -1071,9 +1077,11 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
         nm = "k_layer16<" + bw + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
         f = conv;
     } else if (group == 16 && mode == 5 && !layers_only(n) && n->B >= 4 && n->B <= 9 && (boards + 15) / 16 >= n->ksplit_min &&
-               (boards + 15) / 16 <= n->ksplit_max) {
-        nm = "k_layer16hk<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): a 16-board "
-             "group split over four workgroups by cout pairs, waves split the contraction by input block, weights resident in registers)";
+               (boards + 15) / 16 <= std::max(n->ksplit_max, n->ksplit_max2)) {
+        const bool four = (boards + 15) / 16 <= n->ksplit_max;
+        nm = "k_layer16hk<" + bw + (four ? ", 4" : ", 2") + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
+             "a 16-board group split over " + (four ? "four workgroups by cout pairs" : "two workgroups by cout quads") +
+             ", waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
     } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (boards + 15) / 16 >= 192))) {
         nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "

@@ -6,8 +6,8 @@
 //
 // Here a group is split by OUTPUT CHANNELS instead: workgroup (group, j) computes cout tiles 2j, 2j+1 for ALL cells of
 // the group (KS = 4 workgroups per group, 1024 boards -> 256 workgroups of identical work, no halo rows, nine full row
-// steps each). Its eight waves split the contraction: wave (t, kp) owns cout tile t of the pair and the kp-th 32-channel
-// INPUT block. Consequences:
+// steps each; KS = 2 for 65 .. 128 groups: cout QUADS, two workgroups per group). Its eight waves split the contraction:
+// wave (t, kp) owns cout tile t of the pair and the kp-th 32-channel INPUT block (KS = 2: two blocks). Consequences (KS = 4):
 //   * the wave's weights -- 9 taps x {high, low} of ONE (tile, block) = 18 fragments = 72 VGPRs -- are loaded ONCE per
 //     layer and stay in registers (the other kernels re-stream a tile's 72 KB per board row);
 //   * an input fragment pair read from LDS feeds 27 MFMAs of its wave (all nine taps x three products);
@@ -19,6 +19,14 @@
 //     (BatchNorm, residual, ReLU, fp16 split, store) and then stages the next input row into exactly the blocks it has
 //     just read -- reader and stager of a block are the same wave, so the refill needs no barrier. Two barriers per row
 //     step: end of step (existing) and "partials visible".
+//   * a row step of this kernel is SHORT (225 MFMAs per wave against 900 in the resident kernel), so what the two waves of
+//     a SIMD do besides MFMAs must not coincide: the waves 0-3 run their exchange + epilogue right after the "partials
+//     visible" barrier, their SIMD partners 4-7 half a step later -- one multiplies while the other exchanges; and the
+//     three-row accumulator window rotates by NAME (the step loop is unrolled by three) instead of being shifted through
+//     108 register moves per step. (First version, without both: 13 k cycles per step for 7.8 k of MFMA issue --
+//     profiles/r4c_ksplit_medium_batches.txt.)
+// KS = 2: a wave owns two input blocks; their weights do not fit the registers beside the window, so they stream from L2
+// one (block, tap row) slab ahead exactly as in the resident kernel (six slabs per row step).
 // fp32-equivalent like the other split-fp16 kernels (three fp16 x fp16 products, fp32 accumulate); the summation order
 // over the four input blocks differs from theirs (there: one accumulator over all blocks), i.e. by fp32 rounding.
 // ao_net_set_mode(6) (one arithmetic for every batch size) therefore never plans this kernel.
@@ -26,16 +34,18 @@
 
 namespace ao {
 
-template <int BW>
+template <int BW, int KS>
 __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
-    constexpr int KS = 4;                    // workgroups per group = waves per cout tile
+    static_assert(KS == 2 || KS == 4, "workgroups per group");
+    constexpr int TW = 8 / KS;               // cout tiles of a workgroup
+    constexpr int CB = 4 / KS;               // 32-channel input blocks of a wave
     constexpr int NC32 = 4, NCI = 4, NT = 8; // 128 channels: four 32-channel blocks, eight 16-channel cout tiles
     constexpr int A = BW * BW;
     constexpr int NFR = BW * NCI * 2;        // 1 KB fragments of a staged input row = exchange blocks (8 waves x BW cells)
     static_assert(NFR == 8 * BW, "row fragments and exchange blocks share one index space");
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];   // [2][NFR][64]
 
-    // XCD-aware placement: the four workgroups of a group share its input rows -- same XCD, same L2 (blocks are dealt
+    // XCD-aware placement: the KS workgroups of a group share its input rows -- same XCD, same L2 (blocks are dealt
     // round robin over the 8 XCDs)
     const int groups = a.nch;
     const int bid = blockIdx.x;
@@ -44,8 +54,12 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
     if (grp >= groups) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-    const int t_loc = w & 1, kp = w >> 1;    // cout tile of the pair, input block (= partner index in the exchange)
-    const int tile = j * 2 + t_loc;          // cout tile of the layer
+    const int t_loc = w % TW, kp = w / TW;   // cout tile within the workgroup; partner index in the exchange = input block(s)
+    // the SIMD partner of wave w - 4 exchanges half a step later. (Resident weights only: with streamed weights the MFMA stream
+    // carries counted s_waitcnt vmcnt(N) for its slabs, and an exchange -- staging loads, stores -- under a wave-dependent
+    // branch makes the compiler fall back to vmcnt(0): every slab then waits for the row being staged.)
+    const bool late = CB == 1 && w >= 4;
+    const int tile = j * TW + t_loc;         // cout tile of the layer
     const int kq = lane >> 4, b = lane & 15;
     const int lane16 = lane * 16;
     const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
@@ -59,18 +73,33 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
     const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, static_cast<unsigned>(A) * NCI * 2u * 1024u);
     const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
 
-    // this wave's weights, resident for the whole layer: W[half][tap]
-    half8 W[2][9];
+    // weights. CB == 1: W[half][tap] of the wave's (tile, block), resident for the whole layer. CB == 2: slab (block, tap
+    // row) = 3 taps x {high, low}, double-buffered one slab ahead (a row step has 6 slabs: the parity carries over)
+    half8 W[2][CB == 1 ? 9 : 1];
+    half8 wA[2][CB == 1 ? 1 : 3], wB[2][CB == 1 ? 1 : 3];
+    if constexpr (CB == 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int ub = ((t * NCI + kp) * NT + tile) * 1024;
-        W[0][t] = buf_ld_h8(rs_wh, lane16, ub);
-        W[1][t] = buf_ld_h8(rs_wl, lane16, ub);
+        for (int t = 0; t < 9; ++t) {
+            const int ub = ((t * NCI + kp) * NT + tile) * 1024;
+            W[0][t] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][t] = buf_ld_h8(rs_wl, lane16, ub);
+        }
     }
+    auto load_slab = [&](int sl, half8 (&Wd)[2][CB == 1 ? 1 : 3]) {
+        if constexpr (CB > 1) {
+            const int c = kp * CB + (sl / 3) % CB, dy = sl % 3;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
+                Wd[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+                Wd[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+            }
+        }
+    };
 
     // Blocks this wave READS in the exchange and STAGES afterwards: (writer wave w2, cell i) with the same cout tile
-    // (w2 & 1 == t_loc) and i % 4 == kp. Block index = fragment index = w2 * BW + i.
-    constexpr int NOWN = (BW + KS - 1) / KS;         // cells a wave can own: kp, kp + 4, kp + 8
+    // (w2 % TW == t_loc) and i % KS == kp. Block index = fragment index = w2 * BW + i.
+    constexpr int NOWN = (BW + KS - 1) / KS;         // cells a wave can own: kp, kp + KS, ...
     auto stage_row = [&](int y, uint4* xb) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
@@ -78,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
             for (int o = 0; o < NOWN; ++o) {
                 const int i = kp + KS * o;
                 if (i < BW) {
-                    const int f = (t_loc + 2 * q) * BW + i;
+                    const int f = (t_loc + TW * q) * BW + i;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(xb + f * 64), 16, lane16,
                                                              (y * NFR + f) * 1024, 0, AO_AUX_STAGE);
                 }
@@ -87,30 +116,30 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
     };
 
     float peak = 0.f;
-    f32x4 acc[3][BW];
+    f32x4 acc[3][BW];                        // three output rows; which is which rotates with the step (see step())
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int i = 0; i < BW; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // park this wave's partial tiles of one output row (all cells it does not own) in row buffer xb
+    // park this wave's partial tiles of one output row in row buffer xb (the cells it owns too: their blocks are read by
+    // nobody else, and the window's registers are free for the next row at once)
     auto park = [&](const f32x4 (&row)[BW], uint4* xb) {
 #pragma unroll
-        for (int i = 0; i < BW; ++i)
-            if ((i & (KS - 1)) != kp) xb[(w * BW + i) * 64 + lane] = __builtin_bit_cast(uint4, row[i]);
+        for (int i = 0; i < BW; ++i) xb[(w * BW + i) * 64 + lane] = __builtin_bit_cast(uint4, row[i]);
     };
-    // owner side of the exchange for output row yo: own[o] = this wave's partial of cell kp + 4 o (copied out of the
-    // accumulator window before it moved on); rh / rl = the residual, requested by the caller ahead of the barrier
-    auto finish = [&](int yo, const f32x4 (&own)[NOWN], const uint4* xb, const half4 (&rh)[NOWN], const half4 (&rl)[NOWN]) {
+    // owner side of the exchange for output row yo (rh / rl = the residual of the owned cells)
+    auto finish = [&](int yo, const uint4* xb, const half4 (&rh)[NOWN], const half4 (&rl)[NOWN]) {
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const int i = kp + KS * o;
             if (i >= BW) continue;
             f32x4 p[KS];
 #pragma unroll
-            for (int q = 0; q < KS; ++q)
-                p[q] = (q == kp) ? own[o] : __builtin_bit_cast(f32x4, xb[((t_loc + 2 * q) * BW + i) * 64 + lane]);
-            const f32x4 c = ((p[0] + p[1]) + p[2]) + p[3];     // fixed order over the input blocks
+            for (int q = 0; q < KS; ++q) p[q] = __builtin_bit_cast(f32x4, xb[((t_loc + TW * q) * BW + i) * 64 + lane]);
+            f32x4 c = p[0] + p[1];                             // fixed order over the partners = input blocks
+#pragma unroll
+            for (int q = 2; q < KS; ++q) c = c + p[q];
             float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
             if (RES) {
 #pragma unroll
@@ -139,102 +168,146 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
             rl[o] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
         }
     };
-    // the MFMAs of input cell (s, xi): 3 tap rows x 3 tap columns x 3 products of this wave's input block
-    auto ldx = [&](const uint4* xs, int xi, int half) -> half8 {
-        return __builtin_bit_cast(half8, xs[((xi * NCI + kp) * 2 + half) * 64 + lane]);
+    auto ldx = [&](const uint4* xs, int xi, int c, int half) -> half8 {
+        return __builtin_bit_cast(half8, xs[((xi * NCI + c) * 2 + half) * 64 + lane]);
     };
-    auto cell = [&](int s, int xi, const half8 xh, const half8 xl) {
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yo = s + 1 - dy;
-                if (yo < 0 || yo >= BW) continue;   // (uniform)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int i = xi - dx + 1;
-                    if (i < 0 || i >= BW) continue;
-                    acc[2 - dy][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[pr == 1 ? 1 : 0][dy * 3 + dx], pr == 2 ? xl : xh,
-                                                                           acc[2 - dy][i], 0, 0, 0);
-                }
-            }
-        }
-    };
-    // this wave's own cell kp + 4 o of an accumulator row, picked with value selects (a register array must not be
-    // indexed by the wave-uniform but dynamic kp)
-    auto pick = [&](const f32x4 (&row)[BW], int o) -> f32x4 {
-        f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < BW; ++i)
-            if (i == kp + KS * o) r = row[i];
-        return r;
-    };
-
-    // prologue: input row 0
+    // prologue: input row 0, the first weight slab
     stage_row(0, s_x);
+    load_slab(0, wA);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    f32x4 own[NOWN];                         // this wave's partials of the cells it owns, of the output row in exchange
+    if constexpr (CB == 1) {
+        // The resident weights HAVE arrived (the wait above), but the compiler's wait-count pass does not read inline
+        // assembly: without a use it can see, it guards their first use inside the step loop with s_waitcnt vmcnt(N) -- and
+        // in the steady state that N covers the staging loads of the row in flight, so every row step stalled until its
+        // successor had landed (the first build of this kernel: 2 x its MFMA time). A no-op "use" of every fragment here
+        // makes the pass place its wait now.
 #pragma unroll
-    for (int o = 0; o < NOWN; ++o) own[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < BW; ++s) {
+        for (int t = 0; t < 9; ++t) {
+            asm volatile("" ::"v"(W[0][t]));
+            asm volatile("" ::"v"(W[1][t]));
+        }
+    }
+
+    // One row step. PH = s % 3 names the accumulator rows: output row s-1 (tap row dy = 2) is acc[PH], row s is
+    // acc[(PH+1) % 3], row s+1 is acc[(PH+2) % 3]; after the step acc[PH] is complete, is parked, and becomes row s+2.
+    auto step = [&](const int s, auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
         const uint4* xs = s_x + static_cast<size_t>(s & 1) * NFR * 64;          // input row s
         uint4* xn = s_x + static_cast<size_t>((s + 1) & 1) * NFR * 64;          // partials of output row s-2, then input row s+1
-        half4 rh[NOWN], rl[NOWN];
-        if (s >= 2) load_res(s - 2, rh, rl);                                     // in flight under the first cell's MFMAs
-        else if (s + 1 < BW) stage_row(s + 1, xn);                               // nothing to exchange yet: stage at once
-        half8 xh = ldx(xs, 0, 0), xl = ldx(xs, 0, 1);
-#pragma unroll
-        for (int xi = 0; xi < BW; ++xi) {
-            half8 nh = xh, nl = xl;
-            if (xi + 1 < BW) {
-                nh = ldx(xs, xi + 1, 0);
-                nl = ldx(xs, xi + 1, 1);
+        if (s < 2 && s + 1 < BW) stage_row(s + 1, xn);                           // nothing to exchange yet: stage at once
+        auto exchange = [&]() {
+            // (the residual's round trip is covered by the SIMD partner, which multiplies while this wave exchanges)
+            half4 rh[NOWN], rl[NOWN];
+            load_res(s - 2, rh, rl);
+            finish(s - 2, xn, rh, rl);
+            if (s + 1 < BW) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // my reads of the blocks are done: refill them
+                stage_row(s + 1, xn);
             }
-            cell(s, xi, xh, xl);
-            xh = nh;
-            xl = nl;
             __builtin_amdgcn_sched_barrier(0);
-            if (xi == 0 && s >= 2) {
-                // "partials visible": every wave parked its tiles (end of the previous step) before this barrier
+        };
+        // after the first unit: "partials visible" (every wave parked its tiles at the end of the previous step); the waves
+        // 0-3 exchange now, their SIMD partners after the unit `late_at`
+        auto sync_point = [&](int unit, int late_at) {
+            if (s < 2) return;
+            if (unit == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                finish(s - 2, own, xn, rh, rl);
-                if (s + 1 < BW) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my reads of the blocks are done: refill them
-                    stage_row(s + 1, xn);
+                if (!late) exchange();
+            }
+            if (unit == late_at && late) exchange();
+        };
+        if constexpr (CB == 1) {
+            half8 xh = ldx(xs, 0, kp, 0), xl = ldx(xs, 0, kp, 1);
+#pragma unroll
+            for (int xi = 0; xi < BW; ++xi) {
+                half8 nh = xh, nl = xl;
+                if (xi + 1 < BW) {
+                    nh = ldx(xs, xi + 1, kp, 0);
+                    nl = ldx(xs, xi + 1, kp, 1);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int yo = s + 1 - dy;
+                        if (yo < 0 || yo >= BW) continue;   // (uniform)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int i = xi - dx + 1;
+                            if (i < 0 || i >= BW) continue;
+                            acc[(PH + 2 - dy) % 3][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                W[pr == 1 ? 1 : 0][dy * 3 + dx], pr == 2 ? xl : xh, acc[(PH + 2 - dy) % 3][i], 0, 0, 0);
+                        }
+                    }
+                }
+                xh = nh;
+                xl = nl;
+                __builtin_amdgcn_sched_barrier(0);
+                sync_point(xi, BW / 2);
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < CB * 3; ++sl) {
+                const int cb = sl / 3, dy = sl % 3;
+                const int c = kp * CB + cb;
+                half8 (&wc)[2][3] = (sl & 1) ? wB : wA;
+                half8 (&wn)[2][3] = (sl & 1) ? wA : wB;
+                load_slab(sl + 1, wn);
+                const int yo = s + 1 - dy;
+                if (yo >= 0 && yo < BW) {   // (uniform)
+                    half8 xh = ldx(xs, 0, c, 0), xl = ldx(xs, 0, c, 1);
+#pragma unroll
+                    for (int xi = 0; xi < BW; ++xi) {
+                        half8 nh = xh, nl = xl;
+                        if (xi + 1 < BW) {
+                            nh = ldx(xs, xi + 1, c, 0);
+                            nl = ldx(xs, xi + 1, c, 1);
+                        }
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int i = xi - dx + 1;
+                                if (i < 0 || i >= BW) continue;
+                                acc[(PH + 2 - dy) % 3][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                                    wc[pr == 1 ? 1 : 0][dx], pr == 2 ? xl : xh, acc[(PH + 2 - dy) % 3][i], 0, 0, 0);
+                            }
+                        }
+                        xh = nh;
+                        xl = nl;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                sync_point(sl, CB * 3 / 2);
             }
         }
         // end of the row step: my share of row s+1 has landed, everybody is done reading row s
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (s >= 1) {
-            // output row s-1 is complete in acc[0]: park the partials in the buffer of row s (free now), keep my own cells
-            park(acc[0], const_cast<uint4*>(xs));
-#pragma unroll
-            for (int o = 0; o < NOWN; ++o) own[o] = pick(acc[0], o);
+            // output row s-1 is complete in acc[PH]: park the partials in the buffer of row s (free now)
+            park(acc[PH], const_cast<uint4*>(xs));
         }
 #pragma unroll
-        for (int i = 0; i < BW; ++i) {
-            acc[0][i] = acc[1][i];
-            acc[1][i] = acc[2][i];
-            acc[2][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < BW; ++i) acc[PH][i] = f32x4{0.f, 0.f, 0.f, 0.f};   // ... and it becomes output row s+2
+    };
+    for (int s0 = 0; s0 < BW; s0 += 3) {
+        step(s0, std::integral_constant<int, 0>{});
+        if (s0 + 1 < BW) step(s0 + 1, std::integral_constant<int, 1>{});
+        if (s0 + 2 < BW) step(s0 + 2, std::integral_constant<int, 2>{});
     }
-    // the last two output rows: BW-2 is parked in the buffer of row BW-1, BW-1 sits in acc[0] and goes to the other one
+    // the last two output rows: BW-2 is parked in the buffer of row BW-1; BW-1 sits in the window and goes to the other one
     {
+        constexpr int PL = ((BW - 1) % 3 + 1) % 3;    // after the last step (phase (BW-1) % 3) row BW-1 is acc[phase + 1]
         uint4* x7 = s_x + static_cast<size_t>((BW - 1) & 1) * NFR * 64;
         uint4* x8 = s_x + static_cast<size_t>(BW & 1) * NFR * 64;
-        f32x4 own8[NOWN];
-#pragma unroll
-        for (int o = 0; o < NOWN; ++o) own8[o] = pick(acc[0], o);
-        park(acc[0], x8);
+        park(acc[PL], x8);
         half4 rh[NOWN], rl[NOWN], rh8[NOWN], rl8[NOWN];
-        if (BW >= 2) load_res(BW - 2, rh, rl);
+        load_res(BW - 2, rh, rl);
         load_res(BW - 1, rh8, rl8);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (BW >= 2) finish(BW - 2, own, x7, rh, rl);
-        finish(BW - 1, own8, x8, rh8, rl8);
+        finish(BW - 2, x7, rh, rl);
+        finish(BW - 1, x8, rh8, rl8);
     }
     if (peak > 65504.f) atomicOr(L.ovf, 1);
 }

@@ -78,9 +78,10 @@ __global__ __launch_bounds__(1024) void k_step_board(TreeParams p, StepNet f, co
         }
     };
     if (w == 0) {
-        expand_backup_game<NCH>(p, g, s_ord, s_prior, s_tab);
+        GameHdr hdr;
+        expand_backup_game<NCH>(p, g, s_ord, s_prior, s_tab, &hdr);
         wsync();
-        select_game<NCH>(p, g, s_mt, s_lin);
+        select_game<NCH>(p, g, s_mt, s_lin, &hdr);
     } else {
         load_a(w % nt);
     }

@@ -237,6 +237,13 @@ struct MtDev {
         pos = *pos_ptr;
         in_lds = false;
     }
+    __device__ void open_at(uint32_t* mt_row, int32_t* pos_ptr, uint32_t* lds_buf, int known_pos) {   // the position is in a register already
+        g_mt = mt_row;
+        g_pos = pos_ptr;
+        lds = lds_buf;
+        pos = known_pos;
+        in_lds = false;
+    }
 
     // regenerate all 624 words (wave-parallel through LDS), write the state back to HBM
     __device__ void twist() {
@@ -384,23 +391,35 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
 // ----------------------------------------------------------------------------------------------
 // k_select
 // ----------------------------------------------------------------------------------------------
+// What select_game needs to know about its game before the first level. When expansion + backup of the previous simulation
+// ran in the same wave just before (k_expand_select, k_step_board), that code has loaded or produced every one of these
+// values and hands them over in registers: re-reading them was one more dependent memory round trip at the head of every
+// descent (AO_PROF, one game: 5.6 k of the tree step's 23 k cycles).
+struct GameHdr {
+    int valid = 0;
+    int is_active, done, target, arena, root_node, batch_row, mtpos;
+};
+
 template <int NCH>
-__device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr) {
+__device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr,
+                                            const GameHdr* hdr = nullptr) {
     const int lane = lane_id();
     AO_TT(3);
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
     // overlap them with), so every step requests all it can in ONE trip: first the game header ...
-    const int is_active = p.active ? p.active[g] : 1;
-    const int done = p.sims_done[g], target = p.sims_target[g];
-    const int arena = p.cur[g];
-    int node = p.root_node[g];
-    const int batch_row = p.row_of_game ? p.row_of_game[g] : g;
+    const bool have = hdr != nullptr && hdr->valid;
+    const int is_active = have ? hdr->is_active : (p.active ? p.active[g] : 1);
+    const int done = have ? hdr->done : p.sims_done[g], target = have ? hdr->target : p.sims_target[g];
+    const int arena = have ? hdr->arena : p.cur[g];
+    int node = have ? hdr->root_node : p.root_node[g];
+    const int batch_row = have ? hdr->batch_row : (p.row_of_game ? p.row_of_game[g] : g);
     if (!is_active || done >= target) {
         if (lane == 0) p.leaf_status[g] = LS_IDLE;
         return;
     }
     MtDev mt;
-    mt.open(p.mt + static_cast<size_t>(g) * 624, p.mtpos + g, s_mt);
+    if (have) mt.open_at(p.mt + static_cast<size_t>(g) * 624, p.mtpos + g, s_mt, hdr->mtpos);
+    else mt.open(p.mt + static_cast<size_t>(g) * 624, p.mtpos + g, s_mt);
 
     int depth = 0;
     int status = LS_EXPAND_ROOT;
@@ -642,7 +661,7 @@ __device__ __forceinline__ double pairwise_sum_dev(const double* a, int n) {
 // ----------------------------------------------------------------------------------------------
 template <int NCH>
 __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const int g, uint8_t* s_ord /*[256]*/,
-                                                   double* s_prior /*[256]*/, int16_t* s_tab /*[256]*/) {
+                                                   double* s_prior /*[256]*/, int16_t* s_tab /*[256]*/, GameHdr* hdr = nullptr) {
     const int lane = lane_id();
     // one memory round trip for everything that depends only on the game: leaf record, evaluation,
     // the first 64 path entries (see select_game on why the trips are batched)
@@ -654,6 +673,16 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
     const int done = p.sims_done[g];
     PosR lp = pos_load(p.leaf_pos + g);
     const int row = p.row_of_game ? p.row_of_game[g] : g;
+    if (hdr) {   // the next selection's header, in the same round trip (see GameHdr); `done` / `root_node` are updated below
+        hdr->is_active = p.active ? p.active[g] : 1;
+        hdr->target = p.sims_target[g];
+        hdr->root_node = p.root_node[g];
+        hdr->mtpos = p.mtpos[g];
+        hdr->arena = arena;
+        hdr->batch_row = row;
+        hdr->done = done;
+        hdr->valid = 1;
+    }
     const float v_eval = p.value[row];
     float pol[NCH];
 #pragma unroll
@@ -668,6 +697,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         if (newn >= p.cap) {
             if (lane == 0) { atomicOr(&p.err[g], ERR_NODE_CAP); p.sims_done[g] = p.sims_target[g]; }
+            if (hdr) hdr->done = hdr->target;
             return;
         }
         const int L = legal_order<NCH>(lp, p.A, s_ord, s_tab);
@@ -719,6 +749,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
             if (status == LS_EXPAND) p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
             else p.root_node[g] = newn;
         }
+        if (hdr && status == LS_EXPAND_ROOT) hdr->root_node = newn;
         v = v_eval;
     }
     // backup (agents.py:223-239): the edge into the leaf gets -v (or +1 for a terminal leaf,
@@ -739,6 +770,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         p.Q[idx] = __fdiv_rn(w, static_cast<float>(n));
     }
     if (lane == 0) p.sims_done[g] = done + 1;
+    if (hdr) hdr->done = done + 1;
 }
 
 

@@ -54,10 +54,11 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     const int g = blockIdx.x * kGamesPerWG + w;
     if (g >= p.G) return;
     AO_TT(0);
-    expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w]);
+    GameHdr hdr;
+    expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w], &hdr);
     wsync();
     AO_TT(1);
-    select_game<NCH>(p, g, s_mt[w]);
+    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr);
     AO_TT(2);
 }
 

@@ -178,12 +178,14 @@ def test_full_size_batch_all_paths_agree():
     net.close()
 
 
-@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 1024, 321), (4, 9, 1000, 77), (2, 9, 390, 5), (10, 9, 512, 9), (3, 7, 640, 12),
-                                             (2, 5, 1024, 3), (1, 4, 700, 8), (2, 8, 777, 6), (2, 6, 512, 4)])
+@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 1024, 321), (4, 9, 1000, 77), (2, 9, 900, 5), (10, 9, 960, 9), (3, 7, 1024, 12),
+                                             (2, 5, 1024, 3), (1, 4, 1000, 8), (2, 8, 911, 6), (2, 6, 1024, 4),
+                                             (4, 9, 2048, 21), (4, 9, 1040, 22), (2, 9, 1999, 23), (10, 9, 1536, 24), (3, 7, 1300, 25),
+                                             (2, 5, 2048, 26), (1, 4, 1700, 27), (2, 8, 1111, 28)])
 def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
-    """Medium batches (24 .. 64 groups of 16 boards, boards up to 9x9) run their trunk convs as k_layer16hk: a group split
-    over four workgroups by cout pairs, the eight waves of a workgroup splitting the contraction by input block, partial
-    tiles exchanged through LDS (net_layer_ksplit.hpp). Checked against the per-layer kernel it replaces (mode 6), the
+    """Medium batches (56 .. 128 groups of 16 boards, boards up to 9x9) run their trunk convs as k_layer16hk: a group split
+    over four workgroups by cout pairs (up to 64 groups) or two by cout quads (65 .. 128), the eight waves of a workgroup
+    splitting the contraction by input block, partial tiles exchanged through LDS (net_layer_ksplit.hpp). Checked against the per-layer kernel it replaces (mode 6), the
     fp32-MFMA kernels (mode 4: no fp16 anywhere) and torch fp32; twice, bit-identical (the exchange adds in a fixed order);
     ragged last group (batch not a multiple of 16), residual and non-residual layers, in-place second conv of a block."""
     import torch
@@ -203,16 +205,16 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
         p, v = net(xt)
         torch.cuda.synchronize()
         if mode == 5:
-            assert net.dominant_kernel(batch)[0].startswith("k_layer16hk<%d>" % B), net.dominant_kernel(batch)[0]
+            assert net.dominant_kernel(batch)[0].startswith("k_layer16hk<%d, %d>" % (B, 4 if batch <= 1024 else 2)), net.dominant_kernel(batch)[0]
         p, v = p.cpu().numpy(), v.cpu().numpy()
         assert np.isfinite(p).all() and np.isfinite(v).all() and net.status() == 0
         if mode in outs:
             np.testing.assert_array_equal(outs[mode][0], p)
             np.testing.assert_array_equal(outs[mode][1], v)
         outs[mode] = (p, v)
-    for m in (6, 4):
-        assert np.abs(outs[5][0] - outs[m][0]).max() < 2e-5, m
-        assert np.abs(outs[5][1] - outs[m][1]).max() < 2e-5, m
+    for m in (6, 4):       # (two fp32-equivalent evaluations of a 10-block golden-vector network differ by up to 3e-5)
+        assert np.abs(outs[5][0] - outs[m][0]).max() < (5e-5 if nb > 6 else 2e-5), m
+        assert np.abs(outs[5][1] - outs[m][1]).max() < (5e-5 if nb > 6 else 2e-5), m
     idx = rs.choice(batch, 128, replace=False)
     idx[:4] = [0, 15, batch - 1, batch - (batch % 16 or 16)]        # first group, last (ragged) group
     with torch.no_grad():
