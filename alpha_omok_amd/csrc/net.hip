@@ -67,8 +67,10 @@ struct ao_net {
     int* d_status = nullptr;                       // bit 0: an activation left the fp16 range in the split-fp16 trunk
     bool attr_l[16][2] = {}, attr_done[16] = {}, lds_attr_done[16] = {}, attr_k[16] = {};
     // groups for which the trunk convs of the per-layer path run as k_layer16hk: [ksplit_min, ksplit_max] with four workgroups per
-    // group (KS = 4), (ksplit_max, ksplit_max2] with two (KS = 2). AO_KSPLIT=lo,hi4,hi2 overrides (0,0,0 = off)
-    int ksplit_min = 56, ksplit_max = 64, ksplit_max2 = 128;
+    // group (KS = 4: 768 .. 1024 boards, -2 .. -17 % against k_layer16h), (ksplit_max, ksplit_max2] with two (KS = 2: built and
+    // correct, but no faster than k_layer16h at 1280 .. 2048 boards -- profiles/r4e_ksplit_medium_batches.txt -- so not planned
+    // by default). AO_KSPLIT=lo,hi4,hi2 overrides (0,0,0 = off; 1,64,128 also plans KS = 2)
+    int ksplit_min = 48, ksplit_max = 64, ksplit_max2 = 0;
     int force_xt = 0, force_nch = 0;               // AO_XT / AO_NCH: tiling overrides for timing experiments (read at create)  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
     bool timing = false;
@@ -278,6 +280,14 @@ static void launch_trunk16(ao_net* n, const float* in_il, int groups, float* pol
     if (n->timing) timer_end(n, idx, s);
 }
 
+#if AO_KO == 14 || AO_KO == 15
+// data-like knock-outs (net_trunk_h16.hpp, AO_KO): the activation buffers hold pseudo-random split-fp16 pairs from the start
+__global__ void k_ko_fill(uint4* buf, size_t nquads) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < nquads; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        buf[i] = ao::ao_ko_fragment(static_cast<unsigned>(i), (i >> 6) & 1);
+}
+#endif
+
 static int ensure_workspace(ao_net* n, int boards) {
     boards = (boards + 31) / 32 * 32;
     if (boards <= n->ws_boards) return 0;
@@ -289,6 +299,11 @@ static int ensure_workspace(ao_net* n, int boards) {
         net_alloc(n, &n->tmp_p, static_cast<size_t>(boards) * n->A) || net_alloc(n, &n->tmp_v, boards))
         return 1;
     n->ws_boards = boards;
+#if AO_KO == 14 || AO_KO == 15
+    hipLaunchKernelGGL(k_ko_fill, dim3(2048), dim3(256), 0, 0, reinterpret_cast<uint4*>(n->act_x), act / 4);
+    hipLaunchKernelGGL(k_ko_fill, dim3(2048), dim3(256), 0, 0, reinterpret_cast<uint4*>(n->act_t), act / 4);
+    NET_HIP(n, hipDeviceSynchronize());
+#endif
     return 0;
 }
 

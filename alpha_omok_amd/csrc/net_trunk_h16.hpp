@@ -75,10 +75,39 @@ __device__ unsigned long long ao_prof[8 * 12];
 // their bytes (staged by lanes 0-31 only, stored / re-read as 4 bytes per lane: the traffic of a 3-byte activation format
 // without its conversion work; BUT the unstaged half of every low fragment then keeps conv1's zeros in LDS, and an MFMA
 // on zeros draws less power), 12 the same traffic with the staged 512 bytes loaded twice so that every operand stays
-// data-like. Measured: profiles/r1j_trunk16h_phase_timing.txt, r3a_trunk16h_bytes_ko.txt
+// data-like. Round 4 re-takes 3 and 4 with DATA-LIKE operands (the round-2 builds froze or zeroed what the MFMAs read and measured
+// MFMA power, not traffic): 13 = 3 with the LDS row buffers pre-filled with pseudo-random activations (half of them zero, like
+// post-ReLU data) that are then never refreshed; 14 = 4 with the activation buffers in HBM pre-filled the same way (net.hip
+// ensure_workspace), so the rows staged are data-like although no epilogue ever writes them; 15 = both. Same switches in the
+// per-layer kernel (trunk_h_layer_tile). Measured: profiles/r1j_trunk16h_phase_timing.txt, r3a_trunk16h_bytes_ko.txt,
+// r4f_ko_datalike.txt
 #ifndef AO_KO
 #define AO_KO 0
 #endif
+#define AO_KO_NOSTAGE (AO_KO == 3 || AO_KO == 13 || AO_KO == 15)
+#define AO_KO_NOEPI (AO_KO == 4 || AO_KO == 14 || AO_KO == 15)
+// pseudo-random post-ReLU-like activation pair for the data-like knock-outs: half zeros, else a high half in [2^-6, 2) with a
+// full 10-bit mantissa; the low half a 2^-11-scaled copy (as the residue of a split would be)
+__device__ __forceinline__ unsigned ao_ko_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint4 ao_ko_fragment(unsigned seed, bool low) {
+    unsigned wd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned out = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned r = ao_ko_hash(seed * 8u + k * 2u + h);
+            const unsigned e = (low ? 4u : 15u) - ((r >> 10) & 7u);          // exponent field: 8 .. 15 (low: 11 binades below)
+            const unsigned v = (r & 0x80000000u) ? 0u : ((e << 10) | (r & 0x3ffu));
+            out |= v << (16 * h);
+        }
+        wd[k] = out;
+    }
+    return make_uint4(wd[0], wd[1], wd[2], wd[3]);
+}
 #if AO_KO != 0 && !defined(AO_PROF) && !defined(AO_WRONG_RESULTS_OK)
 #error "AO_KO builds compute wrong results on purpose: timing only, build them with -DAO_PROF"
 #endif
@@ -357,7 +386,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         }
     } else if (FMT == 1) {
         stage_pairs(0, s_x, 0, (NPAIR + NT - 1) / NT);
-    } else {
+    } else if (!(AO_KO == 13 || AO_KO == 15)) {
 #pragma unroll
         for (int k = 0; k < (NFR + NT - 1) / NT; ++k) {
             const int f = tile + NT * k;
@@ -395,14 +424,14 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
             half8 (&w)[2][3] = (slab & 1) ? wB : wA;
             half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
             load_w(slab + 1, wn);
-            if (dy == 1 && AO_KO != 3 && FMT == 1 && !FIRST) {
+            if (dy == 1 && !AO_KO_NOSTAGE && FMT == 1 && !FIRST) {
                 // next input row into LDS, a share of this wave's fragment pairs per block
                 // (the share staged one block earlier has landed long ago: it is expanded first, so that the wait the
                 // compiler puts in front of its LDS reads does not cover the loads issued below)
                 constexpr int K2 = (NPAIR / NT + NCI - 1) / (NCI > 1 ? NCI - 1 : 1);   // shares in blocks 0 .. NCI-2, the last block only expands
                 if (c > 0 && AO_KO != 11) expand_pairs(xn, (c - 1) * K2, c * K2);   // (AO_KO 11: no expansion, timing only)
                 if (c + 1 < NCI) stage_pairs(yn, xn, c * K2, (c + 1) * K2);
-            } else if (BITS && AO_KO != 3 && AO_CONV1_SPLIT) {
+            } else if (BITS && !AO_KO_NOSTAGE && AO_CONV1_SPLIT) {
                 // conv1 on bit planes: the next row's plane bytes are requested in the first slab of the row and turned
                 // into fragments in the last one, so the byte loads' round trip is covered by a slab of MFMAs (a conv1
                 // row has only three slabs; load and LDS write in the same slab stalled every row)
@@ -422,7 +451,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
                         }
                     }
                 }
-            } else if (dy == 1 && AO_KO != 3) {
+            } else if (dy == 1 && (!AO_KO_NOSTAGE || FIRST)) {
                 // next input row into LDS, a share per block (always-executed slab)
 #pragma unroll
                 for (int k = 0; k < (NFR / NT + NCI) / NCI; ++k) {
@@ -474,7 +503,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         // row are done
         row_arrive(s_cnt, lane);
 #endif
-        if (yi >= 1 && (AO_KO != 4 || yi == 1)) epilogue(yi - 1);
+        if (yi >= 1 && (!AO_KO_NOEPI || (AO_KO == 4 && yi == 1))) epilogue(yi - 1);
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
             acc[0][i] = acc[1][i];
@@ -496,7 +525,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         AO_ACC(3, t_r2, t_r3);
     }
     AO_T(t_c);
-    epilogue(BW - 1);
+    if (!AO_KO_NOEPI || FIRST) epilogue(BW - 1);
     if (peak > (FMT == 1 ? 65504.f * kLo8Scale : 65504.f)) atomicOr(L.ovf, 1);
     // layer boundary inside the workgroup (see k_trunk16)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -638,6 +667,9 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
 
     const int y0 = yb > 0 ? yb - 1 : 0;          // input rows that feed output rows [yb, ye)
     const int y1 = ye < BW ? ye : BW - 1;
+    if ((AO_KO == 13 || AO_KO == 15) && !FIRST) {   // data-like LDS rows that are never refreshed
+        for (int f = tile; f < 2 * NFR; f += NT) s_x[f * 64 + lane] = ao_ko_fragment((blockIdx.x * 2u * NFR + f) * 64u + lane, f & 1);
+    } else
     stage(y0, s_x);
     load_w(0, wA);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -651,7 +683,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             half8 (&w)[2][3] = (slab & 1) ? wB : wA;
             half8 (&wn)[2][3] = (slab & 1) ? wA : wB;
             load_w(slab + 1, wn);
-            if (slab == 1 && yi < y1) stage(yi + 1, xn);
+            if (slab == 1 && yi < y1 && (!AO_KO_NOSTAGE || FIRST)) stage(yi + 1, xn);
             const int yo = yi + 1 - dy;
             if (yo >= yb && yo < ye) {   // (uniform)
                 half8 xh = __builtin_bit_cast(half8, xs[((0 * NCI + c) * NSP + 0) * 64 + lane]);
@@ -681,7 +713,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (yi - 1 >= yb) epilogue(yi - 1);
+        if (yi - 1 >= yb && (!AO_KO_NOEPI || FIRST)) epilogue(yi - 1);
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             acc[0][i] = acc[1][i];
@@ -690,7 +722,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (ye == BW) epilogue(BW - 1);
+    if (ye == BW && (!AO_KO_NOEPI || FIRST)) epilogue(BW - 1);
     if (peak > 65504.f) atomicOr(L.ovf, 1);
 }
 
@@ -744,6 +776,7 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     // arrival counter of the split row barrier: behind the two row buffers (kTrunkHCntOffset), monotonic over the launch
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_x + static_cast<size_t>(2) * BW * NC32 * 2 * 64);
     if (threadIdx.x == 0) *s_cnt = 0u;   // (published by the first barrier of conv1's prologue)
+    const bool ko_fill = AO_KO == 13 || AO_KO == 15;
     // conv1: fp32 planes -> x
     AO_T(t0);
     if (INK == 2)
@@ -753,6 +786,11 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
         TrunkHLayerFn<BW, NC32, 1, 1, FMT>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
                                       s_cnt, 0u);
     AO_T(t1);
+    if (ko_fill) {   // data-like LDS rows for the trunk layers, never refreshed (see AO_KO)
+        __syncthreads();
+        for (int f = tile; f < 2 * BW * NC32 * 2; f += NC32 * 2) s_x[f * 64 + lane] = ao_ko_fragment((grp * 4u * BW * NC32 + f) * 64u + lane, f & 1);
+        __syncthreads();
+    }
 #ifdef AO_PROF
     for (int k = 0; k < 12; ++k) prof[k] = 0;
 #endif

@@ -178,14 +178,15 @@ def test_full_size_batch_all_paths_agree():
     net.close()
 
 
-@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 1024, 321), (4, 9, 1000, 77), (2, 9, 900, 5), (10, 9, 960, 9), (3, 7, 1024, 12),
-                                             (2, 5, 1024, 3), (1, 4, 1000, 8), (2, 8, 911, 6), (2, 6, 1024, 4),
+@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 1024, 321), (4, 9, 1000, 77), (2, 9, 800, 5), (10, 9, 960, 9), (3, 7, 1024, 12),
+                                             (2, 5, 1024, 3), (1, 4, 1000, 8), (2, 8, 911, 6), (2, 6, 768, 4),
                                              (4, 9, 2048, 21), (4, 9, 1040, 22), (2, 9, 1999, 23), (10, 9, 1536, 24), (3, 7, 1300, 25),
                                              (2, 5, 2048, 26), (1, 4, 1700, 27), (2, 8, 1111, 28)])
-def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
-    """Medium batches (56 .. 128 groups of 16 boards, boards up to 9x9) run their trunk convs as k_layer16hk: a group split
-    over four workgroups by cout pairs (up to 64 groups) or two by cout quads (65 .. 128), the eight waves of a workgroup
-    splitting the contraction by input block, partial tiles exchanged through LDS (net_layer_ksplit.hpp). Checked against the per-layer kernel it replaces (mode 6), the
+def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed, monkeypatch):
+    """Medium batches (48 .. 64 groups of 16 boards, boards up to 9x9) run their trunk convs as k_layer16hk: a group split
+    over four workgroups by cout pairs, the eight waves of a workgroup splitting the contraction by input block, partial tiles
+    exchanged through LDS (net_layer_ksplit.hpp). The two-workgroup form (cout quads, 65 .. 128 groups: correct, not faster,
+    not planned by default) is exercised through AO_KSPLIT. Checked against the per-layer kernel it replaces (mode 6), the
     fp32-MFMA kernels (mode 4: no fp16 anywhere) and torch fp32; twice, bit-identical (the exchange adds in a fixed order);
     ragged last group (batch not a multiple of 16), residual and non-residual layers, in-place second conv of a block."""
     import torch
@@ -198,7 +199,9 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
     x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
     x[:, 4] = (rs.rand(batch, 1, 1) < 0.5).astype(np.float32)
     xt = torch.from_numpy(x).cuda()
+    monkeypatch.setenv("AO_KSPLIT", "48,64,128")
     net = ref.to_native(0)
+    monkeypatch.delenv("AO_KSPLIT")
     outs = {}
     for mode in (5, 6, 4, 5):
         net.set_mode(mode)
@@ -212,9 +215,10 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed):
             np.testing.assert_array_equal(outs[mode][0], p)
             np.testing.assert_array_equal(outs[mode][1], v)
         outs[mode] = (p, v)
-    for m in (6, 4):       # (two fp32-equivalent evaluations of a 10-block golden-vector network differ by up to 3e-5)
-        assert np.abs(outs[5][0] - outs[m][0]).max() < (5e-5 if nb > 6 else 2e-5), m
-        assert np.abs(outs[5][1] - outs[m][1]).max() < (5e-5 if nb > 6 else 2e-5), m
+    for m in (6, 4):       # (two fp32-equivalent evaluations of a 10-block golden-vector network differ by up to 1e-4: the
+        # tower of synthetic weights amplifies fp32 rounding; the bar is the comparison with torch fp32 below)
+        assert np.abs(outs[5][0] - outs[m][0]).max() < (1.5e-4 if nb > 6 else 2e-5), m
+        assert np.abs(outs[5][1] - outs[m][1]).max() < (1.5e-4 if nb > 6 else 2e-5), m
     idx = rs.choice(batch, 128, replace=False)
     idx[:4] = [0, 15, batch - 1, batch - (batch % 16 or 16)]        # first group, last (ragged) group
     with torch.no_grad():
