@@ -368,3 +368,49 @@ def test_carry_over_pool_numbers_episodes_across_calls_and_ranks():
         more = pool.take_next(limit + n_call)                   # ... and goes on when the limit moves (the next call)
         nxt = [first + 3 * n_call + e for e in range(rank, n_call, world)]
         assert more == (nxt[0] if nxt else -1)
+
+
+def test_run_schedule_constants_scale_the_reference_loop(monkeypatch):
+    """main.run is the reference's loop (main.py:377-414): N_SELFPLAY games, then ONE game + one training pass per iteration.
+    GAMES_PER_ITER / TRAIN_STEPS (None = the reference) scale it to thousands of concurrent games: the games of the later
+    iterations, and the mini-batches of a pass instead of one per new sample."""
+    import random
+    from alpha_omok_amd import main
+    calls = []
+    monkeypatch.setattr(main, "Agent", object())                     # (configured)
+    monkeypatch.setattr(main, "self_play", lambda n: calls.append(("play", n)))
+    monkeypatch.setattr(main, "train", lambda e, i: calls.append(("train", i)))
+    monkeypatch.setattr(main, "load_data", lambda a, b: None)
+    monkeypatch.setattr(main, "save_model", lambda *a, **k: None)
+    monkeypatch.setattr(main, "save_dataset", lambda *a, **k: None)
+    monkeypatch.setattr(main, "start_iter", 0)
+    monkeypatch.setattr(main, "GAMES_PER_ITER", None)
+    assert main.run(total_iter=3, n_selfplay=7) == 3
+    assert calls == [("play", 7), ("play", 1), ("train", 1), ("play", 1), ("train", 2)]
+    calls.clear()
+    monkeypatch.setattr(main, "GAMES_PER_ITER", 2048)
+    main.run(total_iter=2, n_selfplay=100)
+    assert calls == [("play", 100), ("play", 2048), ("train", 1)]
+    # TRAIN_STEPS replaces len(cur_memory) as the number of mini-batches of a pass
+    import torch
+    from alpha_omok_amd.pvnet import PVNet
+    monkeypatch.undo()
+    main.configure(board_size=3, n_mcts=4, n_blocks=1, out_planes=32, seed=1, gpu=0)
+    rs = np.random.RandomState(0)
+    main.rep_memory.clear(); main.cur_memory.clear()
+    for _ in range(200):
+        pi = rs.rand(9); pi /= pi.sum()
+        main.rep_memory.append(((rs.rand(5, 3, 3) < 0.3).astype(np.float64), pi, float(rs.choice([-1.0, 0.0, 1.0]))))
+    main.cur_memory.extend(list(main.rep_memory)[:3])
+    random.seed(4)
+    main.step = 0
+    try:
+        main.TRAIN_STEPS, main.BATCH_SIZE = 5, 16
+        losses = main.train(1, 1)
+        assert len(losses) == 5 and main.step == 5
+        main.TRAIN_STEPS = None
+        losses = main.train(1, 2)
+        assert len(losses) == 3 and main.step == 8                   # the reference: one mini-batch per new sample
+    finally:
+        main.TRAIN_STEPS, main.BATCH_SIZE = None, 32
+        main.rep_memory.clear(); main.cur_memory.clear()
