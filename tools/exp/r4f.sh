@@ -1,6 +1,7 @@
 # round 4: the staging / epilogue knock-outs of round 2 re-taken with DATA-LIKE operands (AO_KO 13 / 14 / 15; 3 / 4 = the round-2 builds,
 # whose MFMA operands froze or went to zero) for the resident 9x9 trunk (4096 boards, 4 blocks, fmt 0) and the per-layer 15x15 kernel
 # (1024 boards, 10 blocks); package power and shader clock beside each
+hipcc --offload-arch=gfx950 -O3 tools/tree_layout_latency.hip -o /tmp/tll 2>/dev/null && /tmp/tll > gpurun_out/r4f_tree_layout_latency.txt 2>&1; cat gpurun_out/r4f_tree_layout_latency.txt
 run() {  # $1 boards $2 blocks $3 board
 python - "$1" "$2" "$3" <<'PY' &
 import sys, os, time
