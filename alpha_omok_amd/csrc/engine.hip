@@ -185,7 +185,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         // happens to be free when the engine is created -- whether re-rooting has to forget subtrees (ao_trim_stats) must
         // not depend on the GPU's other tenants.
         const int Ap_ = (c.board * c.board + 15) / 16 * 16;
-        const double node_bytes = Ap_ * 25.0 + 80.0;     // N, W, Q, CH 4 B + P 8 B + ACT 1 B per edge slot, + the position
+        const double node_bytes = ao::node_rec_bytes(Ap_);   // the node record: P 8 B + N, Q, CH, W 4 B + ACT 1 B per edge slot + the position, padded to 128
         size_t free_b = 0, total_b = 0;
         long cap = 16L * (c.sims + 1);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
@@ -197,7 +197,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         // 16 x (sims + 1) -- for sharp (trained) policies that keep more of the tree from move to move. 4096 games x
         // 400 sims on a 288 GB part: ~3400 nodes per arena instead of 1604. The chosen value is reported by ao_node_cap.
         const int Ap_ = (c.board * c.board + 15) / 16 * 16;
-        const double node_bytes = Ap_ * 25.0 + 80.0;     // N, W, Q, CH 4 B + P 8 B + ACT 1 B per edge slot, + the position
+        const double node_bytes = ao::node_rec_bytes(Ap_);   // the node record: P 8 B + N, Q, CH, W 4 B + ACT 1 B per edge slot + the position, padded to 128
         size_t free_b = 0, total_b = 0;
         long cap = 4L * (c.sims + 1);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -225,10 +225,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.c_puct = c.c_puct;
 
     const size_t slots = static_cast<size_t>(2) * G * p.cap;
-    if (dev_alloc(e, &p.N, slots * Ap) || dev_alloc(e, &p.W, slots * Ap) || dev_alloc(e, &p.Q, slots * Ap) ||
-        dev_alloc(e, &p.P, slots * Ap) || dev_alloc(e, &p.CH, slots * Ap) || dev_alloc(e, &p.ACT, slots * Ap) ||
-        dev_alloc(e, &p.meta, slots))
-        return 1;
+    p.rec = ao::node_rec_bytes(Ap);                        // one interleaved record per node (engine_types.hpp)
+    if (dev_alloc(e, &p.arena, slots * p.rec)) return 1;
     if (dev_alloc(e, &p.cur, G) || dev_alloc(e, &p.root_node, G) || dev_alloc(e, &p.nodes_used, G) ||
         dev_alloc(e, &p.rootpos, G) || dev_alloc(e, &p.mt, static_cast<size_t>(G) * 624) ||
         dev_alloc(e, &p.mtpos, G) || dev_alloc(e, &p.noise_buf, static_cast<size_t>(G) * Ap) ||
@@ -798,15 +796,14 @@ int ao_get_root_children(ao_engine* e, int g, int32_t* act, double* n, double* w
     if (root < 0) return 0;
     const size_t slot = ao::node_slot(e->tp, cur, g, root);
     ao::Pos m;
-    AO_HIP(e, hipMemcpy(&m, e->tp.meta + slot, sizeof(m), hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(&m, ao::nodePos(e->tp, slot), sizeof(m), hipMemcpyDeviceToHost));
     const int L = m.nchild;
     std::vector<int32_t> hn(L); std::vector<float> hw(L), hq(L); std::vector<double> hp(L); std::vector<uint8_t> ha(L);
-    const size_t eb = slot * e->Ap;
-    AO_HIP(e, hipMemcpy(hn.data(), e->tp.N + eb, 4 * L, hipMemcpyDeviceToHost));
-    AO_HIP(e, hipMemcpy(hw.data(), e->tp.W + eb, 4 * L, hipMemcpyDeviceToHost));
-    AO_HIP(e, hipMemcpy(hq.data(), e->tp.Q + eb, 4 * L, hipMemcpyDeviceToHost));
-    AO_HIP(e, hipMemcpy(hp.data(), e->tp.P + eb, 8 * L, hipMemcpyDeviceToHost));
-    AO_HIP(e, hipMemcpy(ha.data(), e->tp.ACT + eb, L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hn.data(), ao::rowN(e->tp, slot), 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hw.data(), ao::rowW(e->tp, slot), 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hq.data(), ao::rowQ(e->tp, slot), 4 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(hp.data(), ao::rowP(e->tp, slot), 8 * L, hipMemcpyDeviceToHost));
+    AO_HIP(e, hipMemcpy(ha.data(), ao::rowACT(e->tp, slot), L, hipMemcpyDeviceToHost));
     for (int i = 0; i < L; ++i) {
         if (act) act[i] = ha[i];
         if (n) n[i] = hn[i];
@@ -828,7 +825,9 @@ int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries)
     if (expanded) *expanded = used;
     if (dict_entries) {
         std::vector<ao::Pos> metas(used);
-        if (used) AO_HIP(e, hipMemcpy(metas.data(), e->tp.meta + ao::node_slot(e->tp, cur, g, 0), sizeof(ao::Pos) * used, hipMemcpyDeviceToHost));
+        // (the positions sit at the end of their node records: a strided copy)
+        if (used) AO_HIP(e, hipMemcpy2D(metas.data(), sizeof(ao::Pos), ao::nodePos(e->tp, ao::node_slot(e->tp, cur, g, 0)), e->tp.rec,
+                                        sizeof(ao::Pos), used, hipMemcpyDeviceToHost));
         int64_t t = used ? 1 : 0;
         for (const ao::Pos& m : metas) t += m.nchild;
         *dict_entries = t;

@@ -38,24 +38,31 @@ enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
 
 // Everything a tree kernel needs, passed by value.
 //
-// Tree arena (structure of arrays in HBM): two arenas per game (ping-pong across re-rooting),
-// each `cap` expanded nodes; a node owns Ap edge slots (A padded to 16). Edge arrays are
-// indexed [(arena*G + g)*cap + node][edge], edge = position in the node's stored child order
-// (the order of utils.legal_actions, agents.py:182,212).
-//   N  int32   visit count   (reference 'n', an integer-valued python float)
-//   W  float   total value   (reference 'w', np.float32 under numpy 2.x)
-//   Q  float   mean value    (reference 'q', np.float32)
-//   P  double  prior         (reference 'p', np.float64)
-//   CH int32   expanded-child node index, CH_UNVISITED or CH_TERMINAL
-//   ACT uint8  action index of the edge
+// Tree arena in HBM: two arenas per game (ping-pong across re-rooting), each `cap` expanded nodes; a node owns Ap edge
+// slots (A padded to 16), edge = position in the node's stored child order (the order of utils.legal_actions,
+// agents.py:182,212). Node (arena, g, node) is record number node_slot() = (arena*G + g)*cap + node.
+//
+// ONE RECORD PER NODE (round 4; rounds 1-3 kept six separate arrays). A level of the PUCT descent reads a node's P, N, Q, CH,
+// ACT rows and its position -- 2.4 KB -- and the next level depends on it; out of six multi-GB arrays that was seven pages
+// and seven DRAM rows per level, and the descent of a trained network's tree (14 levels, the launch lasting as long as the
+// deepest of 4096 descents) spent 4 - 5 k cycles per level waiting. tools/tree_layout_latency.hip replays the access
+// pattern: 4.07 us per level on the six arrays, 2.11 us on interleaved records of the same footprint. Layout of a record
+// (`rec` bytes, a multiple of 128; the rows the selection reads are contiguous at its start):
+//   P   f64[Ap]  prior         (reference 'p', np.float64)                                   offset 0
+//   N   i32[Ap]  visit count   (reference 'n', an integer-valued python float)               8 Ap
+//   Q   f32[Ap]  mean value    (reference 'q', np.float32)                                   12 Ap
+//   CH  i32[Ap]  expanded-child node index, CH_UNVISITED or CH_TERMINAL                      16 Ap
+//   ACT u8[Ap]   action index of the edge                                                    20 Ap
+//   W   f32[Ap]  total value   (reference 'w', np.float32 under numpy 2.x; backup only)      21 Ap
+//   Pos          the node's position (80 B)                                                  25 Ap
 struct TreeParams {
     int B, A, Ap, C, win_mark, G, cap, maxd, noise;
     int keep_max;  // most nodes a re-rooting keeps: cap - sims - 1, so the next move's expansions always fit
     int nchq;  // channel quads of the interleaved input batch: ceil(C/4) rounded up to even
     int nchq_live;  // quads the plane encoder writes: nchq, or ceil(C/4) when the padding quads are known to be zero
     double c_puct;
-    // arena
-    int32_t* N; float* W; float* Q; double* P; int32_t* CH; uint8_t* ACT; Pos* meta;
+    // arena: one record of `rec` bytes per node (see above; row accessors below)
+    unsigned char* arena; unsigned rec;
     // per game
     int32_t* cur;         // which arena is live
     int32_t* root_node;   // node index of the search root, -1 if the root is not expanded
@@ -93,6 +100,15 @@ struct TreeParams {
 __host__ __device__ inline size_t node_slot(const TreeParams& p, int arena, int g, int node) {
     return (static_cast<size_t>(arena) * p.G + g) * p.cap + node;
 }
+__host__ __device__ inline unsigned node_rec_bytes(int Ap) { return (25u * Ap + 80u + 127u) & ~127u; }
+__host__ __device__ inline unsigned char* node_rec(const TreeParams& p, size_t slot) { return p.arena + slot * p.rec; }
+__host__ __device__ inline double* rowP(const TreeParams& p, size_t slot) { return reinterpret_cast<double*>(node_rec(p, slot)); }
+__host__ __device__ inline int32_t* rowN(const TreeParams& p, size_t slot) { return reinterpret_cast<int32_t*>(node_rec(p, slot) + 8u * p.Ap); }
+__host__ __device__ inline float* rowQ(const TreeParams& p, size_t slot) { return reinterpret_cast<float*>(node_rec(p, slot) + 12u * p.Ap); }
+__host__ __device__ inline int32_t* rowCH(const TreeParams& p, size_t slot) { return reinterpret_cast<int32_t*>(node_rec(p, slot) + 16u * p.Ap); }
+__host__ __device__ inline uint8_t* rowACT(const TreeParams& p, size_t slot) { return node_rec(p, slot) + 20u * p.Ap; }
+__host__ __device__ inline float* rowW(const TreeParams& p, size_t slot) { return reinterpret_cast<float*>(node_rec(p, slot) + 21u * p.Ap); }
+__host__ __device__ inline Pos* nodePos(const TreeParams& p, size_t slot) { return reinterpret_cast<Pos*>(node_rec(p, slot) + 25u * p.Ap); }
 
 // parameters of both heads (model.py:34-73); BatchNorm folded into sc3/sh3
 struct HeadParams {

@@ -504,6 +504,13 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         row_arrive(s_cnt, lane);
 #endif
         if (yi >= 1 && (!AO_KO_NOEPI || (AO_KO == 4 && yi == 1))) epilogue(yi - 1);
+        else if (yi >= 1 && (AO_KO == 14 || AO_KO == 15)) {
+            // (no epilogue, but the row's accumulators stay "used": without a consumer the compiler deletes the MFMAs that
+            // feed them -- the first data-like no-epilogue build ran in 0.27 ms, and round 2's AO_KO=4 had lost part of its
+            // MFMAs the same way)
+#pragma unroll
+            for (int i = 0; i < BW; ++i) asm volatile("" ::"v"(acc[0][i]));
+        }
 #pragma unroll
         for (int i = 0; i < BW; ++i) {
             acc[0][i] = acc[1][i];
@@ -714,6 +721,10 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
             __builtin_amdgcn_sched_barrier(0);
         }
         if (yi - 1 >= yb && (!AO_KO_NOEPI || FIRST)) epilogue(yi - 1);
+        else if (yi - 1 >= yb && (AO_KO == 14 || AO_KO == 15)) {
+#pragma unroll
+            for (int i = 0; i < XT; ++i) asm volatile("" ::"v"(acc[0][i]));   // (see trunk_h_layer)
+        }
 #pragma unroll
         for (int i = 0; i < XT; ++i) {
             acc[0][i] = acc[1][i];

@@ -431,11 +431,15 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         for (;;) {
             AO_TT(4);
             const size_t slot = node_slot(p, arena, g, node);
-            const size_t eb = slot * p.Ap;
+            const double* rP = rowP(p, slot);
+            const int32_t* rN = rowN(p, slot);
+            const float* rQ = rowQ(p, slot);
+            int32_t* rCH = rowCH(p, slot);
+            const uint8_t* rACT = rowACT(p, slot);
             // ... then, per level, the node record together with all five edge rows. The rows are Ap
             // wide, so the addresses do not depend on the child count; lanes past it are masked after
             // the loads (CH and ACT of the chosen edge then come from a lane shuffle, not from memory).
-            const PosR m = pos_load(p.meta + slot);
+            const PosR m = pos_load(nodePos(p, slot));
             int n[NCH], chv[NCH], acv[NCH];
             float qv[NCH];
             double pv[NCH];
@@ -443,11 +447,11 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             for (int c = 0; c < NCH; ++c) {
                 const int e = lane + 64 * c;
                 const bool in = e < p.Ap;
-                n[c] = in ? p.N[eb + e] : 0;
-                qv[c] = in ? p.Q[eb + e] : 0.f;
-                pv[c] = in ? p.P[eb + e] : 0.0;
-                chv[c] = in ? p.CH[eb + e] : CH_UNVISITED;
-                acv[c] = in ? static_cast<int>(p.ACT[eb + e]) : 0;
+                n[c] = in ? rN[e] : 0;
+                qv[c] = in ? rQ[e] : 0.f;
+                pv[c] = in ? rP[e] : 0.0;
+                chv[c] = in ? rCH[e] : CH_UNVISITED;
+                acv[c] = in ? static_cast<int>(rACT[e]) : 0;
             }
             const int L = m.nchild;
             int tot = 0;
@@ -527,7 +531,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             const int w = win_after_move(lp, a, p.B, p.win_mark);
             if (w != 0) {
                 status = LS_TERMINAL;
-                if (lane == 0) p.CH[eb + esel] = CH_TERMINAL;
+                if (lane == 0) rCH[esel] = CH_TERMINAL;
             } else {
                 status = LS_EXPAND;
             }
@@ -711,7 +715,6 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         const double sum = pairwise_sum_dev(s_prior, p.A);  // prior_prob.sum() (agents.py:189)
         const bool add_noise = p.noise && status == LS_EXPAND_ROOT;  // agents.py:191-204
         const size_t slot = node_slot(p, arena, g, newn);
-        const size_t eb = slot * p.Ap;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int i = lane + 64 * c;
@@ -723,12 +726,12 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
                     const double t2 = __dmul_rn(0.25, p.noise_buf[static_cast<size_t>(g) * p.Ap + i]);
                     pr = __dadd_rn(t1, t2);
                 }
-                p.N[eb + i] = 0;
-                p.W[eb + i] = 0.f;
-                p.Q[eb + i] = 0.f;
-                p.P[eb + i] = pr;
-                p.CH[eb + i] = CH_UNVISITED;
-                p.ACT[eb + i] = static_cast<uint8_t>(a);
+                rowN(p, slot)[i] = 0;
+                rowW(p, slot)[i] = 0.f;
+                rowQ(p, slot)[i] = 0.f;
+                rowP(p, slot)[i] = pr;
+                rowCH(p, slot)[i] = CH_UNVISITED;
+                rowACT(p, slot)[i] = static_cast<uint8_t>(a);
             }
         }
         // link from the parent edge (the last path entry)
@@ -744,9 +747,9 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         }
         if (lane == 0) {
             lp.nchild = L;
-            pos_store(p.meta + slot, lp);
+            pos_store(nodePos(p, slot), lp);
             p.nodes_used[g] = newn + 1;
-            if (status == LS_EXPAND) p.CH[node_slot(p, arena, g, pn) * p.Ap + pe] = newn;
+            if (status == LS_EXPAND) rowCH(p, node_slot(p, arena, g, pn))[pe] = newn;
             else p.root_node[g] = newn;
         }
         if (hdr && status == LS_EXPAND_ROOT) hdr->root_node = newn;
@@ -762,12 +765,12 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         float s;
         if (terminal) s = (cnt & 1) ? -1.f : 1.f;
         else s = (cnt & 1) ? v : -v;
-        const size_t idx = node_slot(p, arena, g, nd) * p.Ap + e;
-        const int n = p.N[idx] + 1;
-        const float w = __fadd_rn(p.W[idx], s);
-        p.N[idx] = n;
-        p.W[idx] = w;
-        p.Q[idx] = __fdiv_rn(w, static_cast<float>(n));
+        const size_t bs = node_slot(p, arena, g, nd);
+        const int n = rowN(p, bs)[e] + 1;
+        const float w = __fadd_rn(rowW(p, bs)[e], s);
+        rowN(p, bs)[e] = n;
+        rowW(p, bs)[e] = w;
+        rowQ(p, bs)[e] = __fdiv_rn(w, static_cast<float>(n));
     }
     if (lane == 0) p.sims_done[g] = done + 1;
     if (hdr) hdr->done = done + 1;

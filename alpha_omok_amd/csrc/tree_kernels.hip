@@ -74,15 +74,14 @@ __global__ __launch_bounds__(64) void k_begin_move(TreeParams p) {
     const int node = p.root_node[g];
     if (!(p.gflags[g] & 1) || node < 0) return;
     const size_t slot = node_slot(p, p.cur[g], g, node);
-    const int L = p.meta[slot].nchild;
-    const size_t eb = slot * p.Ap;
+    const int L = nodePos(p, slot)->nchild;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int i = lane + 64 * c;
         if (i < L) {
-            const double t1 = __dmul_rn(0.75, p.P[eb + i]);
+            const double t1 = __dmul_rn(0.75, rowP(p, slot)[i]);
             const double t2 = __dmul_rn(0.25, p.noise_buf[static_cast<size_t>(g) * p.Ap + i]);
-            p.P[eb + i] = __dadd_rn(t1, t2);
+            rowP(p, slot)[i] = __dadd_rn(t1, t2);
         }
     }
 }
@@ -108,16 +107,15 @@ __global__ __launch_bounds__(64) void k_end_move(TreeParams p) {
     int tot = 0;
     if (node >= 0) {
         const size_t slot = node_slot(p, p.cur[g], g, node);
-        const int L = p.meta[slot].nchild;
-        const size_t eb = slot * p.Ap;
+        const int L = nodePos(p, slot)->nchild;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int i = lane + 64 * c;
             if (i < L) {
-                const int a = p.ACT[eb + i];
-                const int n = p.N[eb + i];
+                const int a = rowACT(p, slot)[i];
+                const int n = rowN(p, slot)[i];
                 s_vis[a] = n;
-                s_pol[a] = p.P[eb + i];
+                s_pol[a] = rowP(p, slot)[i];
                 tot += n;
             }
         }
@@ -191,13 +189,13 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
         const int o = s_old[head];
         const size_t so = node_slot(p, oa, g, o);
         const size_t sn = node_slot(p, na, g, head);
-        const PosR m = pos_load(p.meta + so);
+        const PosR m = pos_load(nodePos(p, so));
         const int L = m.nchild;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e = lane + 64 * c;
             const bool valid = e < L;
-            const int ch = valid ? p.CH[so * p.Ap + e] : CH_UNVISITED;
+            const int ch = valid ? rowCH(p, so)[e] : CH_UNVISITED;
             const bool ex = valid && ch >= 0;
             const uint64_t mk = __ballot(ex);
             const int idx = tail + __popcll(mk & lanes_below());
@@ -208,18 +206,18 @@ __device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old)
             const bool drop = ex && !keep;
             if (keep) s_old[idx] = ch;
             if (valid) {
-                p.CH[sn * p.Ap + e] = keep ? idx : (drop ? CH_UNVISITED : ch);
-                p.N[sn * p.Ap + e] = drop ? 0 : p.N[so * p.Ap + e];
-                p.W[sn * p.Ap + e] = drop ? 0.f : p.W[so * p.Ap + e];
-                p.Q[sn * p.Ap + e] = drop ? 0.f : p.Q[so * p.Ap + e];
-                p.P[sn * p.Ap + e] = p.P[so * p.Ap + e];
-                p.ACT[sn * p.Ap + e] = p.ACT[so * p.Ap + e];
+                rowCH(p, sn)[e] = keep ? idx : (drop ? CH_UNVISITED : ch);
+                rowN(p, sn)[e] = drop ? 0 : rowN(p, so)[e];
+                rowW(p, sn)[e] = drop ? 0.f : rowW(p, so)[e];
+                rowQ(p, sn)[e] = drop ? 0.f : rowQ(p, so)[e];
+                rowP(p, sn)[e] = rowP(p, so)[e];
+                rowACT(p, sn)[e] = rowACT(p, so)[e];
             }
             const int kept = __popcll(__ballot(keep));
             dropped += __popcll(mk) - kept;
             tail += kept;
         }
-        if (lane == 0) pos_store(p.meta + sn, m);
+        if (lane == 0) pos_store(nodePos(p, sn), m);
         __syncthreads();
     }
     if (lane == 0) {
@@ -279,15 +277,15 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
     int ch = CH_UNVISITED;
     if (node >= 0) {
         const size_t slot = node_slot(p, p.cur[g], g, node);
-        const int L = p.meta[slot].nchild;
+        const int L = nodePos(p, slot)->nchild;
         int found = -1;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int i = lane + 64 * c;
-            const uint64_t mk = __ballot(i < L && p.ACT[slot * p.Ap + i] == action);
+            const uint64_t mk = __ballot(i < L && rowACT(p, slot)[i] == action);
             if (found < 0 && mk) found = 64 * c + __ffsll(static_cast<long long>(mk)) - 1;
         }
-        if (found >= 0) ch = p.CH[slot * p.Ap + found];
+        if (found >= 0) ch = rowCH(p, slot)[found];
     }
     if (ch >= 0 && w == 0) {
         reroot<NCH>(p, g, ch, s_old);
@@ -335,17 +333,17 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games,
         bool next_known = false;
         if (node >= 0) {
             const size_t slot = node_slot(p, p.cur[g], g, node);
-            const int L = p.meta[slot].nchild;
+            const int L = nodePos(p, slot)->nchild;
             int found = -1;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int e = lane + 64 * c;
-                const uint64_t mk = __ballot(e < L && p.ACT[slot * p.Ap + e] == a);
+                const uint64_t mk = __ballot(e < L && rowACT(p, slot)[e] == a);
                 if (found < 0 && mk) found = 64 * c + __ffsll(static_cast<long long>(mk)) - 1;
             }
             if (found >= 0) {
                 next_known = true;  // children of an expanded node are dict entries
-                const int ch = p.CH[slot * p.Ap + found];
+                const int ch = rowCH(p, slot)[found];
                 if (ch >= 0) next = ch;
             }
         }
