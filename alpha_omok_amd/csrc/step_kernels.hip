@@ -42,7 +42,6 @@ __global__ __launch_bounds__(1024) void k_step_board(TreeParams p, StepNet f, co
     __shared__ double s_prior[256];
     __shared__ int16_t s_tab[256];
     __shared__ uint8_t s_lin[256];                                  // bit planes of the new leaf, byte per cell
-    __shared__ __attribute__((aligned(16))) unsigned char s_pf[PfBytes<NCH>::value];   // select_game's speculative next-level copy
     // ... as fp16 0 / 1, 8 planes per cell, with a border of empty cells (entry 0 of the border doubles as "no tap")
     __shared__ __attribute__((aligned(16))) uint4 s_x[(kMaxBoard + 2) * (kMaxBoard + 2)];
     // One workgroup per ROW of the evaluation batch (= per active game; the others were set idle by the move's k_select):
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(1024) void k_step_board(TreeParams p, StepNet f, co
         GameHdr hdr;
         expand_backup_game<NCH>(p, g, s_ord, s_prior, s_tab, &hdr);
         wsync();
-        select_game<NCH>(p, g, s_mt, s_lin, &hdr, p.prefetch ? s_pf : nullptr);
+        select_game<NCH>(p, g, s_mt, s_lin, &hdr);
     } else {
         load_a(w % nt);
     }

@@ -400,28 +400,9 @@ struct GameHdr {
     int is_active, done, target, arena, root_node, batch_row, mtpos;
 };
 
-// LDS scratch of the speculative next-level copy (select_game): one node record of a board with up to 64 * NCH edge slots
-template <int NCH>
-struct PfBytes { static constexpr int value = (25 * 64 * NCH + 80 + 127) & ~127; };
-
-// Copies node record `slot` (its rows P N Q CH ACT W and the position: 25 Ap + 80 bytes) into LDS, asynchronously: LDS-direct
-// buffer loads, 1 KB per instruction, nothing passes through registers. The caller reads the copy only after the wave's
-// outstanding vector-memory operations have completed (the compiler places that wait: it tracks LDS-DMA writes).
-__device__ __forceinline__ void prefetch_record(const TreeParams& p, size_t slot, unsigned char* pf) {
-    const unsigned need = 25u * static_cast<unsigned>(p.Ap) + 80u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(node_rec(p, slot), 0, static_cast<int>(p.rec), 0x00020000);
-    const unsigned lane16 = static_cast<unsigned>(lane_id()) * 16u;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        if (k * 1024u < need && k * 1024u + lane16 < need)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pf + k * 1024), 16, static_cast<int>(lane16),
-                                                     k * 1024, 0, 0);
-    }
-}
-
 template <int NCH>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr,
-                                            const GameHdr* hdr = nullptr, unsigned char* pf = nullptr /* LDS, PfBytes<NCH> */) {
+                                            const GameHdr* hdr = nullptr) {
     const int lane = lane_id();
     AO_TT(3);
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
@@ -443,7 +424,6 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     int depth = 0;
     int status = LS_EXPAND_ROOT;
     unsigned levels = 0, ties = 0;
-    int pf_node = -1;                        // node whose record is (being) copied into `pf`
     PosR lp;
     if (node < 0) {
         lp = pos_load(p.rootpos + g);
@@ -451,51 +431,28 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         for (;;) {
             AO_TT(4);
             const size_t slot = node_slot(p, arena, g, node);
+            const double* rP = rowP(p, slot);
+            const int32_t* rN = rowN(p, slot);
+            const float* rQ = rowQ(p, slot);
             int32_t* rCH = rowCH(p, slot);
-            // ... then, per level, the node record: the position and the five edge rows the PUCT rule reads. The rows are Ap
+            const uint8_t* rACT = rowACT(p, slot);
+            // ... then, per level, the node record together with all five edge rows. The rows are Ap
             // wide, so the addresses do not depend on the child count; lanes past it are masked after
             // the loads (CH and ACT of the chosen edge then come from a lane shuffle, not from memory).
-            PosR m;
+            const PosR m = pos_load(nodePos(p, slot));
             int n[NCH], chv[NCH], acv[NCH];
             float qv[NCH];
             double pv[NCH];
-            if (pf != nullptr && pf_node == node) {
-                // speculation hit: the record was requested a level ago (below) and sits in LDS, or is about to
-                const unsigned ap = static_cast<unsigned>(p.Ap);
-                const double* lP = reinterpret_cast<const double*>(pf);
-                const int32_t* lN = reinterpret_cast<const int32_t*>(pf + 8u * ap);
-                const float* lQ = reinterpret_cast<const float*>(pf + 12u * ap);
-                const int32_t* lCH = reinterpret_cast<const int32_t*>(pf + 16u * ap);
-                const uint8_t* lACT = pf + 20u * ap;
-                m = pos_load(reinterpret_cast<const Pos*>(pf + 25u * ap));
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int e = lane + 64 * c;
-                    const bool in = e < p.Ap;
-                    n[c] = in ? lN[e] : 0;
-                    qv[c] = in ? lQ[e] : 0.f;
-                    pv[c] = in ? lP[e] : 0.0;
-                    chv[c] = in ? lCH[e] : CH_UNVISITED;
-                    acv[c] = in ? static_cast<int>(lACT[e]) : 0;
-                }
-            } else {
-                const double* rP = rowP(p, slot);
-                const int32_t* rN = rowN(p, slot);
-                const float* rQ = rowQ(p, slot);
-                const uint8_t* rACT = rowACT(p, slot);
-                m = pos_load(nodePos(p, slot));
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int e = lane + 64 * c;
-                    const bool in = e < p.Ap;
-                    n[c] = in ? rN[e] : 0;
-                    qv[c] = in ? rQ[e] : 0.f;
-                    pv[c] = in ? rP[e] : 0.0;
-                    chv[c] = in ? rCH[e] : CH_UNVISITED;
-                    acv[c] = in ? static_cast<int>(rACT[e]) : 0;
-                }
+            for (int c = 0; c < NCH; ++c) {
+                const int e = lane + 64 * c;
+                const bool in = e < p.Ap;
+                n[c] = in ? rN[e] : 0;
+                qv[c] = in ? rQ[e] : 0.f;
+                pv[c] = in ? rP[e] : 0.0;
+                chv[c] = in ? rCH[e] : CH_UNVISITED;
+                acv[c] = in ? static_cast<int>(rACT[e]) : 0;
             }
-            pf_node = -1;
             const int L = m.nchild;
             int tot = 0;
 #pragma unroll
@@ -506,36 +463,6 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             }
             tot = wave_sum_i(tot);
             AO_TT(5);
-            if (pf != nullptr) {
-                // Speculation: request the record of the MOST VISITED child now, before the fp64 PUCT arithmetic, the tie
-                // break and the pick -- a sharp (trained) policy sends simulation after simulation down the same principal
-                // variation, and the launch lasts as long as the deepest of its descents: a chain of (memory round trip +
-                // ~3 k cycles of arithmetic) per level. A hit overlaps the two; a miss costs one 2.5 KB read. The copy lands in
-                // LDS (prefetch_record), not in registers: the kernel stays at four waves per SIMD.
-                int nm = 0;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) nm = n[c] > nm ? n[c] : nm;
-                nm = wave_max_i(nm);
-                if (nm > 0) {
-                    int eb = -1;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const uint64_t mk = __ballot(lane + 64 * c < L && n[c] == nm);
-                        if (eb < 0 && mk) eb = 64 * c + __ffsll(static_cast<long long>(mk)) - 1;
-                    }
-                    int cand = CH_UNVISITED;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int cv = __shfl(chv[c], eb & 63);
-                        if ((eb >> 6) == c) cand = cv;
-                    }
-                    if (cand >= 0) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this level's reads of the scratch are done)
-                        prefetch_record(p, node_slot(p, arena, g, cand), pf);
-                        pf_node = cand;
-                    }
-                }
-            }
             // np.sqrt(total_n) (total_n is an exact integer): the device's correctly rounded double sqrt equals the host's for
             // every integer below 2^24 (tools/sqrt_exact.hip, checked exhaustively on the MI355X) -- computed, not looked up: the
             // table read depended on total_n and was one more memory round trip per level of the descent

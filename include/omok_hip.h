@@ -11,7 +11,7 @@
  * thread-safe; all its work is queued on one HIP stream (ao_stream()).
  *
  * A handle owns G concurrent games. Game g has: its move list (the reference's node id without
- * the leading 0), its search tree (an arena in HBM: structure-of-arrays edge rows, one record per expanded node), and its own numpy-legacy
+ * the leading 0), its search tree (structure-of-arrays arena in HBM), and its own numpy-legacy
  * MT19937 stream (the reference's process-global np.random, main.py:60, one per game here).
  */
 #ifndef OMOK_HIP_H
