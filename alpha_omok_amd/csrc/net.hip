@@ -192,6 +192,7 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
     // at 128 boards and 979 / 676 at 256; per-board path vs split-fp16 layers 174 / 246 at 32 boards and 307 / 258
     // at 64 (15x15, 10 blocks: 518 / 501 at 16 boards)
     if (mode == 6) mode = 5;   // mode 6 = mode 5 restricted to the per-layer kernels (layers_only()): one arithmetic for every batch size
+    if (n->planes > 128) mode = 4;   // wide networks: the row-chunked fp32 layer kernels are the one path built for them
     if (mode == 0) {
         const long cells = static_cast<long>(boards) * n->A;
         // (end of round 3, with the activations split once at staging and the fused per-game step: 9x9 per-board vs per-layer
@@ -205,7 +206,7 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
         // row chunks per group: minimise (rounds of workgroups over the CUs) x (rows per chunk)
         long best = -1;
         for (int c = 1; c <= n->B; ++c) {
-            const long rounds = (static_cast<long>(g16) * c + n->num_cu - 1) / n->num_cu;
+            const long rounds = (static_cast<long>(g16) * c * ((n->planes + 127) / 128) + n->num_cu - 1) / n->num_cu;
             const long cost = rounds * ((n->B + c - 1) / c);
             if (best < 0 || cost < best) { best = cost; nch = c; }
         }
@@ -640,7 +641,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.sc = reinterpret_cast<const float4*>(n->conv_sc[l]);
             a.layer.sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
             a.res = res ? 1 : 0; a.cqi = cqi; a.cq_real = cq_real; a.COUT = n->planes; a.nch = nch;
-            const dim3 grid(groups * nch), block(64 * (n->planes / 16));
+            a.nsplit = (n->planes + 127) / 128;           // output channels beyond 128: a second workgroup per (group, chunk)
+            const dim3 grid(groups * nch * a.nsplit), block(64 * std::min(8, n->planes / 16));
             const bool timed = n->timing && l > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
             switch (n->B) {
@@ -739,7 +741,10 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     auto bad = [&](const char* m) { g_net_create_error = m; return 1; };
     if (n_block < 0 || n_block > 64) return bad("n_block out of range");
     if (inplanes < 1 || inplanes > 12) return bad("inplanes must be in 1..12");
-    if (planes < 32 || planes > 128 || planes % 32) return bad("planes must be 32, 64, 96 or 128");
+    // 32 .. 128 planes: every path (128: the split-fp16 MFMA kernels). 160 .. 256: the row-chunked fp32-MFMA layer kernels
+    // (mode 4) for every batch size, a group's output channels split over two workgroups (k_layer16) -- model.py:76-85
+    // takes any `planes`; wider or odd widths stay with the caller's torch module (alpha_omok_amd/evaluator.py)
+    if (planes < 32 || planes > 256 || planes % 32) return bad("planes must be a multiple of 32 in 32 .. 256");
     if (board < 3 || board > ao::kMaxBoard) return bad("board must be in 3..15");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad("no HIP device available");

@@ -654,20 +654,25 @@ struct LayerArgs {
     float4* dst;
     TrunkLayer layer;
     int res, cqi, cq_real, COUT, nch;
+    int nsplit;   // workgroups per (group, row chunk): eight 16-channel output tiles each (networks wider than 128 planes)
 };
 
 template <int BW, int XT>
 __global__ __launch_bounds__(512, 1) void k_layer16(LayerArgs a) {
     constexpr int A = BW * BW;
-    const int grp = blockIdx.x / a.nch;
-    const int c = blockIdx.x - grp * a.nch;
+    const int half = blockIdx.x % a.nsplit;
+    const int rest = blockIdx.x / a.nsplit;
+    const int grp = rest / a.nch;
+    const int c = rest - grp * a.nch;
     const int base = BW / a.nch, extra = BW % a.nch;
     const int yb = c * base + (c < extra ? c : extra);
     const int ye = yb + base + (c < extra ? 1 : 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int ct0 = half * 8 + wave;                  // this wave's 16-channel output tile
+    if (ct0 * 16 >= a.COUT) return;                   // (160 / 192 / 224 planes: the second workgroup has fewer tiles; no barriers below)
     trunk_layer<BW, XT, 1>(a.src, a.dst, a.layer.w, a.layer.sc, a.layer.sh, a.res != 0, a.cqi, a.cq_real, a.COUT,
-                           static_cast<size_t>(grp) * A, wave, lane >> 4, lane & 15, yb, ye);
+                           static_cast<size_t>(grp) * A, ct0, lane >> 4, lane & 15, yb, ye);
 }
 
 }  // namespace ao

@@ -25,16 +25,16 @@ class Evaluator:
 
     def native_net(self, model, board_size, inplanes):
         cfg = pvnet.looks_like_pvnet(model)
-        if cfg is not None and (cfg[2] % 32 or cfg[2] > 128) and cfg[3] == board_size and cfg[1] == inplanes:
-            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward is built for 32 / 64 / 96 / 128
+        if cfg is not None and (cfg[2] % 32 or cfg[2] > 256) and cfg[3] == board_size and cfg[1] == inplanes:
+            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward is built for multiples of 32 up to 256
             if not self._warned_width:
                 import warnings
-                warnings.warn("PVNet with %d planes: the native MI355X forward covers 32, 64, 96 and 128 planes -- this network "
+                warnings.warn("PVNet with %d planes: the native MI355X forward covers multiples of 32 planes up to 256 -- this network "
                               "is evaluated by its own torch module, one call per simulation on the whole leaf batch "
                               "(correct, but several times slower than the MFMA kernels)" % cfg[2], RuntimeWarning, stacklevel=3)
                 self._warned_width = True
             return None
-        if cfg is None or cfg[2] % 32 or cfg[2] > 128 or cfg[3] != board_size or cfg[1] != inplanes:
+        if cfg is None or cfg[2] % 32 or cfg[2] > 256 or cfg[3] != board_size or cfg[1] != inplanes:
             return None
         # the native copy is keyed on the module OBJECT (held through a weak reference: a new module
         # at a recycled address is a different object), its shape and the in-place version counters of

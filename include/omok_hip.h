@@ -159,7 +159,10 @@ int ao_search_stats(ao_engine *e, int64_t *levels, int64_t *ties, int64_t *termi
                     int64_t *evaluated);
 
 /* ---- policy/value network ---- replaces model.PVNet(...).forward in eval() mode
- * (model.py:76-104). Parameters are given under their state_dict names. */
+ * (model.py:76-104). Parameters are given under their state_dict names.
+ * planes: a multiple of 32 in 32 .. 256 (model.py:76-85 takes any width). 128 planes (the reference's OUT_PLANES,
+ * main.py:35) run on the split-fp16 MFMA kernels; 160 .. 256 planes on the row-chunked fp32-MFMA layer kernels for every
+ * batch size, whatever ao_net_set_mode asks for. */
 int  ao_net_create(int n_block, int inplanes, int planes, int board, int device, ao_net **out);
 void ao_net_destroy(ao_net *n);
 const char *ao_net_last_error(const ao_net *n);

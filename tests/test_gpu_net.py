@@ -227,6 +227,48 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed, monkeypatch):
     net.close()
 
 
+@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 256, 40), (1, 5, 192, 700), (2, 15, 160, 24), (3, 9, 224, 1024), (1, 3, 256, 5)])
+def test_wide_networks_run_on_the_fp32_layer_kernels(nb, B, planes, batch):
+    """model.PVNet takes any `planes` (model.py:76-85). 160 .. 256 planes (multiples of 32) run natively on the row-chunked
+    fp32-MFMA layer kernels for every batch size -- a group's output channels beyond 128 go to a second workgroup of k_layer16 --
+    whatever mode is asked for; checked against torch fp32, and through a fused search against the stepwise one."""
+    import torch
+    from alpha_omok_amd.engine import Engine
+    from alpha_omok_amd.pvnet import PVNet
+    sd = pvnet_weights.make_state_dict(nb, 5, planes, B, 40 + planes)
+    ref = PVNet(nb, 5, planes, B)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ref.eval()
+    rs = np.random.RandomState(batch)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x))
+    net = ref.to_native(0)
+    for mode in (0, 3, 5):
+        net.set_mode(mode)
+        assert net.dominant_kernel(batch)[0].startswith("k_layer16<%d>" % B)
+        p, v = net(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert np.abs(p.cpu().numpy() - rp.numpy()).max() < TOL and np.abs(v.cpu().numpy() - rv.numpy()).max() < TOL, mode
+    if batch <= 64 and B >= 5:
+        S, G = 12, min(batch, 8)
+        a, b2 = Engine(B, S, 5, games=G, noise=True), Engine(B, S, 5, games=G, noise=True)
+        seeds = np.arange(G, dtype=np.uint32) + 3
+        a.seed_all(seeds); b2.seed_all(seeds)
+        pi, vis, pol = a.search(net, tau=1)
+        planes_t = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
+        b2.begin_move()
+        while b2.sims_left() > 0:
+            b2.collect_leaves(planes_t.data_ptr()); b2.sync()
+            pp, vv = net(planes_t); torch.cuda.synchronize()
+            b2.apply_evals(pp.data_ptr(), vv.data_ptr())
+        pi2, vis2, pol2 = b2.end_move(np.ones(G, np.int8))
+        np.testing.assert_array_equal(vis, vis2)
+        np.testing.assert_array_equal(pol, pol2)
+        a.close(); b2.close()
+    net.close()
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("nb,B,seed", [(4, 9, 77), (10, 9, 5), (6, 7, 12), (1, 5, 3)])
 def test_resident_trunk_both_activation_formats(nb, B, seed, fmt, monkeypatch):
