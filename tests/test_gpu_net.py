@@ -244,7 +244,7 @@ def test_wide_networks_run_on_the_fp32_layer_kernels(nb, B, planes, batch):
     with torch.no_grad():
         rp, rv = ref(torch.from_numpy(x))
     net = ref.to_native(0)
-    for mode in (0, 3, 5):
+    for mode in (0, 3, 2, 1):
         net.set_mode(mode)
         assert net.dominant_kernel(batch)[0].startswith("k_layer16<%d>" % B)
         p, v = net(torch.from_numpy(x).cuda())
