@@ -180,8 +180,9 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         // below), 16 x holds f <= 0.93 -- what a trained, sharp policy needs, and the reference's dict never forgets
         // (agents.py:52). Measured with a network trained by this engine (profiles/r4_trained_*): 10.5 M move decisions at
         // 16 x without a single trim; one self_play(4096) at 11.4 x: 38 of 259 k re-rootings trimmed. The number is
-        // DETERMINISTIC for a given device model: bounded by 45 % of the device's TOTAL memory for the two arenas (4096
-        // games x 400 sims on a 288 GB MI355X: the full 6416 nodes, 130 GB -- trees are what the HBM is for), not by what
+        // DETERMINISTIC for a given device model: bounded by 40 % of the device's TOTAL memory for the two arenas (4096
+        // games x 400 sims on a 288 GB MI355X: ~5900 nodes = 14.7 x sims, 124 GB -- trees are what the HBM is for, and two
+        // such engines still fit side by side), not by what
         // happens to be free when the engine is created -- whether re-rooting has to forget subtrees (ao_trim_stats) must
         // not depend on the GPU's other tenants.
         const int Ap_ = (c.board * c.board + 15) / 16 * 16;
@@ -189,7 +190,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         size_t free_b = 0, total_b = 0;
         long cap = 16L * (c.sims + 1);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            cap = std::min<long>(cap, static_cast<long>(0.45 * static_cast<double>(total_b) / (2.0 * c.games * node_bytes)));
+            cap = std::min<long>(cap, static_cast<long>(0.40 * static_cast<double>(total_b) / (2.0 * c.games * node_bytes)));
         cap = std::max<long>(cap, 4L * (c.sims + 1));
         c.node_cap = static_cast<int32_t>(std::min<long>(cap, 15000));
     } else if (c.node_cap < 0) {

@@ -73,7 +73,7 @@ _episodes_played = 0
 _trim_seen = [0]
 _trim_base = [0, 0]          # counters of engines that were closed since configure()
 STRICT = False               # configure(strict=True): an arena trim raises TreeTrimmed instead of logging a warning
-NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 16*(sims+1) within 45 % of the HBM; -1: grow into the free HBM)
+NODE_CAP = 0                 # ao_config.node_cap of the self-play engine (0: 16*(sims+1) within 40 % of the HBM; -1: grow into the free HBM)
 last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of every search of the last _play_episodes call
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 # search shape, cumulative since configure(): PUCT levels walked, exact-tie draws, terminal leaves, evaluated leaves over all
@@ -88,7 +88,7 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
               model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
               carry_over=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
-    node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 45 % of the HBM
+    node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 40 % of the HBM
     holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
     strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
     logged and `trim_stats` / self_play's return value carry the counters). reproducible=True evaluates every batch

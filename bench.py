@@ -744,6 +744,9 @@ def main():
                 net10.close()
             except Exception as e:
                 out["ten_block_net"] = {"value": None, "error": repr(e)}
+        # (the main engine's trees -- 124 GB of arena at 4096 games -- are not needed by any leg below: free them before the
+        # legs that build engines of their own)
+        eng.close()
         if world == 1 and not args.no_trained_net and os.path.exists(args.trained_weights) and (B, args.blocks, args.planes) == (9, 4, 128):
             try:
                 out["trained_net"] = trained_net_bench(args, local, args.trained_weights)

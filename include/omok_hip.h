@@ -35,7 +35,7 @@ typedef struct ao_config {
     int32_t inplanes;   /* IN_PLANES = 2*history+1 (main.py:34); 3, 5, 7 or 9                  */
     int32_t games;      /* G concurrent games (1 for a drop-in ZeroAgent)                      */
     int32_t noise;      /* Dirichlet root noise on/off (agents.py:40,49)                       */
-    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = default: 16*(sims+1), bounded by 45 % of
+    int32_t node_cap;   /* expanded-node capacity of one game's arena; 0 = default: 16*(sims+1), bounded by 40 % of
                            the device's TOTAL memory for all games' arenas and never below 4*(sims+1) -- a deterministic
                            number per device model; -1 = grow into the HBM that is free now (a quarter of it, at most
                            16*(sims+1)); see ao_trim_stats, ao_node_cap                                       */
