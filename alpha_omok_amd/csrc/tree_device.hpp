@@ -30,23 +30,54 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Wave reductions on the DPP path (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, row_bcast:15 and row_bcast:31 across them:
+// six VALU instructions, the result in lane 63, handed back through v_readlane as a wave-uniform value). As xor butterflies over
+// ds_bpermute they were 6 (int) / 12 (double) LDS-crossbar round trips with a wait each: ~1 k cycles per level of a descent
+// (AO_PROF "puct"). Integer sums and maxima of non-NaN values do not depend on the order, so the results are the same bits.
+// All 64 lanes must be active (they are: the per-game code is wave-uniform).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWS, 0xf, false); }
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_mov<kDppShr1, 0xf>(0, v);
+    v += dpp_mov<kDppShr2, 0xf>(0, v);
+    v += dpp_mov<kDppShr4, 0xf>(0, v);
+    v += dpp_mov<kDppShr8, 0xf>(0, v);
+    v += dpp_mov<kDppBcast15, 0xa>(0, v);
+    v += dpp_mov<kDppBcast31, 0xc>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
+    auto mx = [](int a, int b) { return b > a ? b : a; };
+    v = mx(v, dpp_mov<kDppShr1, 0xf>(v, v));
+    v = mx(v, dpp_mov<kDppShr2, 0xf>(v, v));
+    v = mx(v, dpp_mov<kDppShr4, 0xf>(v, v));
+    v = mx(v, dpp_mov<kDppShr8, 0xf>(v, v));
+    v = mx(v, dpp_mov<kDppBcast15, 0xa>(v, v));
+    v = mx(v, dpp_mov<kDppBcast31, 0xc>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_max_d(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double t = __hiloint2double(dpp_mov<CTRL, ROWS>(hi, hi), dpp_mov<CTRL, ROWS>(lo, lo));
+    return t > v ? t : v;
 }
+__device__ __forceinline__ double wave_max_d(double v) {
+    v = dpp_max_d<kDppShr1, 0xf>(v);
+    v = dpp_max_d<kDppShr2, 0xf>(v);
+    v = dpp_max_d<kDppShr4, 0xf>(v);
+    v = dpp_max_d<kDppShr8, 0xf>(v);
+    v = dpp_max_d<kDppBcast15, 0xa>(v);
+    v = dpp_max_d<kDppBcast31, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// value of lane `l` (wave-uniform l) as a wave-uniform value: v_readlane, not an LDS-crossbar shuffle
+__device__ __forceinline__ int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 __device__ __forceinline__ uint64_t lanes_below() { return (1ull << lane_id()) - 1ull; }
 
@@ -229,13 +260,24 @@ struct MtDev {
     uint32_t* lds;  // [624]
     int pos;
     bool in_lds;
+    // The next 64 words of the state, one per lane, requested when the stream is opened: a tie-break draw then is a v_readlane,
+    // not a dependent memory round trip (every descent that ends at a freshly expanded node draws: its children all score 0,
+    // agents.py:161-163 -- and the masked rejection takes 1.3 - 2 words per draw).
+    uint32_t win;
+    int win0;
 
+    __device__ void load_window() {
+        win0 = pos;
+        const int i = pos + lane_id();
+        win = g_mt[i < 624 ? i : 623];
+    }
     __device__ void open(uint32_t* mt_row, int32_t* pos_ptr, uint32_t* lds_buf) {
         g_mt = mt_row;
         g_pos = pos_ptr;
         lds = lds_buf;
         pos = *pos_ptr;
         in_lds = false;
+        load_window();
     }
     __device__ void open_at(uint32_t* mt_row, int32_t* pos_ptr, uint32_t* lds_buf, int known_pos) {   // the position is in a register already
         g_mt = mt_row;
@@ -243,6 +285,7 @@ struct MtDev {
         lds = lds_buf;
         pos = known_pos;
         in_lds = false;
+        load_window();
     }
 
     // regenerate all 624 words (wave-parallel through LDS), write the state back to HBM
@@ -287,7 +330,10 @@ struct MtDev {
 
     __device__ uint32_t next32() {  // wave-uniform
         if (pos >= 624) twist();
-        uint32_t y = in_lds ? lds[pos] : g_mt[pos];
+        uint32_t y;
+        if (in_lds) y = lds[pos];
+        else if (static_cast<unsigned>(pos - win0) < 64u) y = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), pos - win0));
+        else y = g_mt[pos];
         ++pos;
         y ^= y >> 11;
         y ^= (y << 7) & 0x9d2c5680u;
@@ -424,6 +470,9 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     int depth = 0;
     int status = LS_EXPAND_ROOT;
     unsigned levels = 0, ties = 0;
+    int path_n[NCH], path_e[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) path_n[c] = path_e[c] = 0;
     PosR lp;
     if (node < 0) {
         lp = pos_load(p.rootpos + g);
@@ -439,20 +488,32 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             // ... then, per level, the node record together with all five edge rows. The rows are Ap
             // wide, so the addresses do not depend on the child count; lanes past it are masked after
             // the loads (CH and ACT of the chosen edge then come from a lane shuffle, not from memory).
-            const PosR m = pos_load(nodePos(p, slot));
-            int n[NCH], chv[NCH], acv[NCH];
+            // The loads are UNCONDITIONAL (lanes past Ap re-read edge Ap-1; everything below masks by e < L <= Ap): written
+            // as `in ? row[e] : 0` every load sat in its own predicated block, and the compiler put a wait behind the position
+            // and behind each byte load -- three to four dependent memory round trips per level instead of one (ISA;
+            // tools/tree_level_latency.hip: a lone wave fetches these rows in 1.1 us, the kernel's levels took ~3).
+            int n[NCH], chv[NCH];
+            unsigned acv[NCH];
             float qv[NCH];
             double pv[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int e = lane + 64 * c;
-                const bool in = e < p.Ap;
-                n[c] = in ? rN[e] : 0;
-                qv[c] = in ? rQ[e] : 0.f;
-                pv[c] = in ? rP[e] : 0.0;
-                chv[c] = in ? rCH[e] : CH_UNVISITED;
-                acv[c] = in ? static_cast<int>(rACT[e]) : 0;
+                const int ec = e < p.Ap ? e : p.Ap - 1;
+                pv[c] = rP[ec];
+                n[c] = rN[ec];
+                qv[c] = rQ[ec];
+                chv[c] = rCH[ec];
+                acv[c] = rACT[ec];
             }
+            PosR m = pos_load(nodePos(p, slot));
+            // (pinned: the compiler otherwise sinks the loads whose first use sits under `e < L` into that block -- a second trip --
+            // and leaves the position's words, used only when the descent ends, to be waited for at the top of the next level)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(pv[c]), "+v"(n[c]), "+v"(qv[c]), "+v"(chv[c]), "+v"(acv[c]));
+#pragma unroll
+            for (int w = 0; w < kBBWords; ++w) asm volatile("" : "+v"(m.bb[0][w]), "+v"(m.bb[1][w]));
+            asm volatile("" : "+v"(mt.win), "+v"(m.last64), "+v"(m.ply), "+v"(m.nchild));
             const int L = m.nchild;
             int tot = 0;
 #pragma unroll
@@ -510,9 +571,11 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                 mt.close();
                 return;
             }
-            if (lane == 0) {
-                p.path_node[static_cast<size_t>(g) * p.maxd + depth] = node;
-                p.path_edge[static_cast<size_t>(g) * p.maxd + depth] = static_cast<int16_t>(esel);
+            // the path stays in registers (entry d in lane d & 63 of chunk d >> 6; maxd = A + 2 <= 64 * NCH) and is written once
+            // after the descent: two stores per level kept the next level's loads behind their acknowledgement
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (lane + 64 * c == depth) { path_n[c] = node; path_e[c] = esel; }
             }
             ++depth;
             ++levels;
@@ -520,7 +583,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             int ch = CH_UNVISITED, a = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int cv = __shfl(chv[c], esel & 63), av = __shfl(acv[c], esel & 63);
+                const int cv = read_lane(chv[c], esel & 63), av = read_lane(static_cast<int>(acv[c]), esel & 63);
                 if ((esel >> 6) == c) { ch = cv; a = av; }
             }
             if (ch >= 0) { node = ch; continue; }
@@ -539,6 +602,14 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         }
     }
     AO_TT(8);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d = lane + 64 * c;
+        if (d < depth) {
+            p.path_node[static_cast<size_t>(g) * p.maxd + d] = path_n[c];
+            p.path_edge[static_cast<size_t>(g) * p.maxd + d] = static_cast<int16_t>(path_e[c]);
+        }
+    }
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         lp.nchild = 0;
         if (lane == 0) pos_store(p.leaf_pos + g, lp);
@@ -667,41 +738,75 @@ template <int NCH>
 __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const int g, uint8_t* s_ord /*[256]*/,
                                                    double* s_prior /*[256]*/, int16_t* s_tab /*[256]*/, GameHdr* hdr = nullptr) {
     const int lane = lane_id();
-    // one memory round trip for everything that depends only on the game: leaf record, evaluation,
-    // the first 64 path entries (see select_game on why the trips are batched)
+    // TWO memory round trips for everything the step needs to know: (1) what depends on the game only -- leaf record, status,
+    // counters, the first 64 * NCH path entries, the next selection's header (GameHdr), the game's row of the evaluation batch --
+    // and (2) that row's policy and value. Every vector load is unconditional (clamped index) and the values are pinned by ONE
+    // empty asm after the last request: written as `cond ? load : 0` each load sat in its own predicated block with a
+    // `s_waitcnt vmcnt(0)` behind it -- six dependent round trips where the comments said one (ISA; AO_PROF: 14 - 20 k cycles
+    // for expansion + backup, most of it here).
     const size_t pbase = static_cast<size_t>(g) * p.maxd;
     const int status = p.leaf_status[g];
     const int arena = p.cur[g];
     const int depth = p.path_len[g];
     const int newn = p.nodes_used[g];
     const int done = p.sims_done[g];
-    PosR lp = pos_load(p.leaf_pos + g);
     const int row = p.row_of_game ? p.row_of_game[g] : g;
-    if (hdr) {   // the next selection's header, in the same round trip (see GameHdr); `done` / `root_node` are updated below
-        hdr->is_active = p.active ? p.active[g] : 1;
-        hdr->target = p.sims_target[g];
-        hdr->root_node = p.root_node[g];
-        hdr->mtpos = p.mtpos[g];
+    const int target = p.sims_target[g];
+    const int root_node = p.root_node[g];
+    const int mtpos = p.mtpos[g];
+    int active_v = 1;
+    if (p.active) active_v = p.active[g];
+    PosR lp = pos_load(p.leaf_pos + g);
+    int pn0[NCH], pe0[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d = lane + 64 * c;
+        const int dc = d < p.maxd ? d : p.maxd - 1;
+        pn0[c] = p.path_node[pbase + dc];
+        pe0[c] = p.path_edge[pbase + dc];
+    }
+    float v_eval = p.value[row];
+    float pol[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int cell = lane + 64 * c;
+        pol[c] = p.policy[static_cast<size_t>(row) * p.A + (cell < p.A ? cell : p.A - 1)];
+    }
+    // the path entries' edge statistics (the backup's read-modify-write below) are requested here, before the expansion's
+    // arithmetic, not after it: the rows of the new node and the parent's CH entry are the only things the expansion writes
+    int bk_n[NCH];
+    float bk_w[NCH];
+    {
+        asm volatile("" : "+v"(pn0[0]), "+v"(pe0[0]));
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = lane + 64 * c;
+            const bool in = d < depth && status != LS_IDLE;
+            const size_t bs = node_slot(p, arena, g, in ? pn0[c] : 0);
+            const int e = in ? pe0[c] : 0;
+            bk_n[c] = rowN(p, bs)[e];
+            bk_w[c] = rowW(p, bs)[e];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(pn0[c]), "+v"(pe0[c]), "+v"(pol[c]), "+v"(bk_n[c]), "+v"(bk_w[c]));
+    asm volatile("" : "+v"(active_v), "+v"(v_eval), "+v"(lp.ply), "+v"(lp.nchild), "+v"(lp.last64), "+v"(lp.bb[0][0]), "+v"(lp.bb[1][0]));
+    if (hdr) {   // the next selection's header (see GameHdr); `done` / `root_node` are updated below
+        hdr->is_active = active_v;
+        hdr->target = target;
+        hdr->root_node = root_node;
+        hdr->mtpos = mtpos;
         hdr->arena = arena;
         hdr->batch_row = row;
         hdr->done = done;
         hdr->valid = 1;
     }
-    const float v_eval = p.value[row];
-    float pol[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int cell = lane + 64 * c;
-        pol[c] = (cell < p.A) ? p.policy[static_cast<size_t>(row) * p.A + cell] : 0.f;
-    }
-    const int pn0 = (lane < p.maxd) ? p.path_node[pbase + lane] : 0;
-    const int pe0 = (lane < p.maxd) ? static_cast<int>(p.path_edge[pbase + lane]) : 0;
     if (status == LS_IDLE) return;
     float v = 0.f;
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         if (newn >= p.cap) {
-            if (lane == 0) { atomicOr(&p.err[g], ERR_NODE_CAP); p.sims_done[g] = p.sims_target[g]; }
-            if (hdr) hdr->done = hdr->target;
+            if (lane == 0) { atomicOr(&p.err[g], ERR_NODE_CAP); p.sims_done[g] = target; }
+            if (hdr) hdr->done = target;
             return;
         }
         const int L = legal_order<NCH>(lp, p.A, s_ord, s_tab);
@@ -737,12 +842,10 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         // link from the parent edge (the last path entry)
         int pn = 0, pe = 0;
         if (status == LS_EXPAND) {
-            if (depth - 1 < 64) {
-                pn = __shfl(pn0, depth - 1);
-                pe = __shfl(pe0, depth - 1);
-            } else {
-                pn = p.path_node[pbase + depth - 1];
-                pe = p.path_edge[pbase + depth - 1];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t_n = read_lane(pn0[c], (depth - 1) & 63), t_e = read_lane(pe0[c], (depth - 1) & 63);
+                if (((depth - 1) >> 6) == c) { pn = t_n; pe = t_e; }
             }
         }
         if (lane == 0) {
@@ -758,16 +861,18 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
     // backup (agents.py:223-239): the edge into the leaf gets -v (or +1 for a terminal leaf,
     // draws included), the sign alternates towards the root. The root's own record is not kept.
     const bool terminal = (status == LS_TERMINAL);
-    for (int d = lane; d < depth; d += 64) {
-        const int nd = (d < 64) ? pn0 : p.path_node[pbase + d];
-        const int e = (d < 64) ? pe0 : static_cast<int>(p.path_edge[pbase + d]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d = lane + 64 * c;
+        if (d >= depth) continue;
         const int cnt = depth - 1 - d;
         float s;
         if (terminal) s = (cnt & 1) ? -1.f : 1.f;
         else s = (cnt & 1) ? v : -v;
-        const size_t bs = node_slot(p, arena, g, nd);
-        const int n = rowN(p, bs)[e] + 1;
-        const float w = __fadd_rn(rowW(p, bs)[e], s);
+        const size_t bs = node_slot(p, arena, g, pn0[c]);
+        const int e = pe0[c];
+        const int n = bk_n[c] + 1;
+        const float w = __fadd_rn(bk_w[c], s);
         rowN(p, bs)[e] = n;
         rowW(p, bs)[e] = w;
         rowQ(p, bs)[e] = __fdiv_rn(w, static_cast<float>(n));
