@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -712,11 +713,22 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // (Replaying the per-simulation launch sequence as a HIP graph was measured and is slower than
     // eager launches here: 71.7 vs 65.7 us per simulation for one game)
     int rc = 0;
+    static const bool launch_timing = getenv("AO_LAUNCH_TIMING") != nullptr;   // developer switch: is the simulation loop host-bound?
+    const auto lt0 = std::chrono::steady_clock::now();
+    const int lt_sims = e->sims_left;
     while (e->sims_left > 0 && rc == 0) {
         rc = one_sim();
         --e->sims_left;
     }
     if (rc) return rc;
+    if (launch_timing) {
+        const auto lt1 = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(e->stream);
+        const auto lt2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "AO_LAUNCH_TIMING %d simulations: launches enqueued in %.1f us each, stream drained %.1f us after the last enqueue\n", lt_sims,
+                std::chrono::duration<double, std::micro>(lt1 - lt0).count() / (lt_sims > 0 ? lt_sims : 1),
+                std::chrono::duration<double, std::micro>(lt2 - lt1).count());
+    }
     // The split-fp16 trunk clamps activations beyond the fp16 range and reports it: the evaluations of such a move are
     // not the fp32-equivalent ones the engine promises (checked before the per-game errors: clamped evaluations are what
     // makes priors degenerate). The move is then searched AGAIN, transparently, on the fp32-MFMA trunk: the games of this
