@@ -97,15 +97,28 @@ __global__ __launch_bounds__(64) void k_rollout_search(RollParams p) {
         Pos cur = root;
         int node = 0, depth = 0, reward = 0;
         for (;;) {
-            const int L = p.NK[gbase + node];
+            // one memory round trip per level: child count, statistics and child links requested together, unconditionally
+            // (lanes past Ap re-read edge Ap-1, everything below masks by e < L), and pinned -- as `e < L ? row[e] : 0` the rows
+            // waited for L, and the chosen edge's CH entry was a third trip after the pick (see select_game, tree_device.hpp)
             const size_t eb = (gbase + node) * p.Ap;
-            int n[NCH], w[NCH];
+            int L = p.NK[gbase + node];
+            int n[NCH], w[NCH], chv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int e = lane + 64 * c;
+                const int ec = e < p.Ap ? e : p.Ap - 1;
+                n[c] = p.N[eb + ec];
+                w[c] = p.W[eb + ec];
+                chv[c] = p.CH[eb + ec];
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(n[c]), "+v"(w[c]), "+v"(chv[c]));
+            asm volatile("" : "+v"(L));
             int tot = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int e = lane + 64 * c;
-                n[c] = (e < L) ? p.N[eb + e] : 0;
-                w[c] = (e < L) ? p.W[eb + e] : 0;
+                if (e >= L) { n[c] = 0; w[c] = 0; }
                 tot += n[c];
             }
             tot = wave_sum_i(tot);
@@ -161,7 +174,12 @@ __global__ __launch_bounds__(64) void k_rollout_search(RollParams p) {
             ++depth;
             const int cell = nth_empty<NCH>(cur, p.A, esel);  // children are the empty cells, ascending
             pos_place(cur, cell);
-            const int ch = p.CH[eb + esel];
+            int ch = CH_UNVISITED;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int cv = read_lane(chv[c], esel & 63);
+                if ((esel >> 6) == c) ch = cv;
+            }
             if (ch >= 0) { node = ch; continue; }
             if (ch == CH_TERMINAL) { reward = 1; break; }
             const int win = win_after_move(cur, cell, p.B, p.win_mark);
