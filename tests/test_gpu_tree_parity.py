@@ -285,6 +285,55 @@ def test_set_root_semantics(oracle):
     eng.close()
 
 
+# a full-board draw on 9x9: 81 moves, colours alternating, never five in a row (found by a randomised greedy search)
+_DRAW_ORDER = [9, 43, 55, 14, 78, 32, 11, 23, 30, 3, 29, 47, 10, 17, 65, 20, 64, 40, 44, 56, 2, 80, 50, 25, 79, 68, 37, 76, 77, 63, 69,
+               34, 46, 49, 4, 74, 62, 61, 31, 13, 53, 75, 18, 59, 72, 42, 24, 28, 12, 35, 7, 5, 60, 73, 27, 15, 22, 45, 33, 6, 66, 0, 39,
+               1, 67, 21, 58, 48, 54, 19, 71, 57, 36, 51, 16, 70, 26, 38, 41, 8, 52]
+
+
+def test_descents_longer_than_64_levels(oracle):
+    """A policy that puts 97 % on the next move of a full-board draw line and a value of 0 makes every simulation extend ONE
+    chain: the descent reaches 81 levels (the whole 9x9 board) and ends at a drawn terminal leaf. select_game keeps the path
+    in registers -- entry d in lane d & 63 of chunk d >> 6 -- and expand_backup_game walks it chunk by chunk: this is the
+    case with a second chunk. Two moves (the second searches the inherited 80-deep chain), visits / priors / pi / stream
+    position against the oracle, bit for bit."""
+    B, S, G = 9, 120, 3
+    A = B * B
+    eng = _engine(B, S, 5, games=G, noise=True)
+    run = HostEvalRunner(eng)
+    rank = {c: i for i, c in enumerate(_DRAW_ORDER)}
+
+    def chain_eval(planes):
+        occupied = (planes[:4].sum(axis=0) > 0).reshape(-1)   # planes 0..3: the two players' stones now and a move ago
+        empty = [c for c in range(A) if not occupied[c]]
+        p = np.full(A, np.float32(0.03 / (A - 1)), np.float32)
+        if empty:
+            p[min(empty, key=lambda c: rank[c])] = np.float32(0.97)
+        return p, np.float32(0.0)
+
+    agents = [oracle.Agent(B, S, 5, noise=True, evaluator=lambda mv, pl, sim: chain_eval(pl)) for _ in range(G)]
+    for g in range(G):
+        eng.seed(g, 500 + g)
+        agents[g].seed(500 + g)
+    roots = [(0,)] * G
+    deep = 0
+    for ply in range(2):
+        pi, vis, pol = run.move(lambda g, sim, pl: chain_eval(pl), tau=np.zeros(G, np.int8))
+        st = eng.search_stats()
+        deep = max(deep, st["levels"] / max(st["evaluated"] + st["terminal"], 1))
+        assert st["terminal"] > 0
+        for g in range(G):
+            opi, ovis, opol = agents[g].get_pi(roots[g], 0)
+            np.testing.assert_array_equal(vis[g], ovis, err_msg="ply %d game %d" % (ply, g))
+            np.testing.assert_array_equal(pol[g], opol)
+            np.testing.assert_array_equal(pi[g], opi)
+            assert eng.get_rng_state(g)[1] == agents[g].rng.pos
+        act, win = eng.play()
+        roots = [roots[g] + (int(act[g]),) for g in range(G)]
+    assert deep > 40, deep   # mean levels per simulation: the chain is 81 long from simulation 81 on
+    eng.close()
+
+
 @pytest.mark.parametrize("B,S,G,blocks", [(9, 400, 4096, 4), (15, 800, 1024, 10)])
 def test_full_size_properties_and_sampled_oracle_parity(oracle, B, S, G, blocks):
     """BASELINE configs[2] size (9x9, 4096 games x 400 sims, 4-block net, group-resident trunk) and the per-GPU
