@@ -164,7 +164,10 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     ao_config& c = e->cfg;
     if (c.board < 3 || c.board > ao::kMaxBoard) return e->fail("board must be in 3..15");
     if (c.win_mark <= 0) c.win_mark = (c.board == 3) ? 3 : 5;
-    if (c.win_mark > 5) return e->fail("win_mark must be <= 5");
+    // (the five-in-a-row test looks four cells each way from the new stone: marks up to 5. A mark ABOVE the board size is also
+    // accepted -- no line can win, the full board is the only end: what ZeroAgent.win_mark = 10 does in the reference, and how the
+    // parity suite gets descents that run the whole board)
+    if (c.win_mark > 5 && c.win_mark <= c.board) return e->fail("win_mark must be <= 5 (or above the board size: no line wins)");
     if (c.sims < 1) return e->fail("sims must be >= 1");
     if (c.inplanes < 3 || c.inplanes > 9 || (c.inplanes % 2) == 0) return e->fail("inplanes must be 3, 5, 7 or 9");
     if (c.games < 1) return e->fail("games must be >= 1");
@@ -220,6 +223,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     ao::TreeParams& p = e->tp;
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
+    p.prefetch = 0;
+    if (const char* v = getenv("AO_TREE_PREFETCH")) p.prefetch = atoi(v) != 0;
     p.keep_max = c.node_cap - c.sims - 1;
     p.nchq = (((c.inplanes + 3) / 4) + 7) & ~7;  // worst case of the network's input layouts (net_plan)
     p.nchq_live = p.nchq;

@@ -30,7 +30,8 @@ typedef struct ao_net ao_net;       /* policy/value ResNet (model.py PVNet) weig
 
 typedef struct ao_config {
     int32_t board;      /* board edge: 3, 9 (env_small.py:18) or 15 (env_regular.py), any 3..15 */
-    int32_t win_mark;   /* 0 = reference rule: 3 if board == 3 else 5 (agents.py:46)            */
+    int32_t win_mark;   /* 0 = reference rule: 3 if board == 3 else 5 (agents.py:46); 1..5, or above
+                           the board size (no line wins: only the full board ends a game)            */
     int32_t sims;       /* num_mcts (agents.py:43; main.py:27 N_MCTS = 400)                    */
     int32_t inplanes;   /* IN_PLANES = 2*history+1 (main.py:34); 3, 5, 7 or 9                  */
     int32_t games;      /* G concurrent games (1 for a drop-in ZeroAgent)                      */

@@ -480,6 +480,9 @@ void oo_agent_destroy(oo_agent *ag)
 }
 
 void oo_agent_set_eval(oo_agent *ag, oo_eval_fn fn, void *ctx) { ag->eval = fn; ag->eval_ctx = ctx; }
+/* ZeroAgent.win_mark is a plain attribute (agents.py:41-44 sets 3 or 5 from the board size); utils.check_win takes it as is:
+   a mark above the board size leaves the full-board draw as the only end of a game. */
+void oo_agent_set_win_mark(oo_agent *ag, int k) { ag->win_mark = k; }
 void oo_agent_use_stub(oo_agent *ag, int mode) { ag->stub_mode = mode; ag->eval = stub_adapter; ag->eval_ctx = ag; }
 oo_rng *oo_agent_rng(oo_agent *ag) { return &ag->rng; }
 long oo_agent_tree_size(oo_agent *ag) { return ag->tree_size; }

@@ -62,6 +62,7 @@ def lib():
     L.oo_agent_create.restype = C.c_void_p
     L.oo_agent_destroy.argtypes = [C.c_void_p]
     L.oo_agent_set_eval.argtypes = [C.c_void_p, EVAL_FN, C.c_void_p]
+    L.oo_agent_set_win_mark.argtypes = [C.c_void_p, C.c_int]
     L.oo_agent_use_stub.argtypes = [C.c_void_p, C.c_int]
     L.oo_agent_rng.argtypes = [C.c_void_p]
     L.oo_agent_rng.restype = P(_Rng)
@@ -258,6 +259,10 @@ class Agent:
 
     def seed(self, s):
         self.rng.seed(s)
+
+    def set_win_mark(self, k):
+        """ZeroAgent.win_mark (agents.py:41-44): stones in a row that win; above the board size only the full board ends a game."""
+        lib().oo_agent_set_win_mark(self._h, int(k))
 
     def reset(self):
         lib().oo_agent_reset(self._h)

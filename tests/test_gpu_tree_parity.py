@@ -295,11 +295,13 @@ def test_descents_longer_than_64_levels(oracle):
     """A policy that puts 97 % on the next move of a full-board draw line and a value of 0 makes every simulation extend ONE
     chain: the descent reaches 81 levels (the whole 9x9 board) and ends at a drawn terminal leaf. select_game keeps the path
     in registers -- entry d in lane d & 63 of chunk d >> 6 -- and expand_backup_game walks it chunk by chunk: this is the
-    case with a second chunk. Two moves (the second searches the inherited 80-deep chain), visits / priors / pi / stream
+    case with a second chunk. Three moves (the later ones search the inherited chain down to its drawn end), visits / priors / pi / stream
     position against the oracle, bit for bit."""
-    B, S, G = 9, 120, 3
+    B, S, G = 9, 200, 3
     A = B * B
-    eng = _engine(B, S, 5, games=G, noise=True)
+    # win_mark above the board size (ZeroAgent.win_mark is a plain attribute in the reference): no line wins, every game ends on
+    # the full board -- off-chain fives would otherwise end most descents early
+    eng = _engine(B, S, 5, games=G, noise=True, win_mark=10)
     run = HostEvalRunner(eng)
     rank = {c: i for i, c in enumerate(_DRAW_ORDER)}
 
@@ -315,22 +317,29 @@ def test_descents_longer_than_64_levels(oracle):
     for g in range(G):
         eng.seed(g, 500 + g)
         agents[g].seed(500 + g)
+        agents[g].set_win_mark(10)
     roots = [(0,)] * G
     deep = 0
-    for ply in range(2):
+    for ply in range(3):
         pi, vis, pol = run.move(lambda g, sim, pl: chain_eval(pl), tau=np.zeros(G, np.int8))
         st = eng.search_stats()
         deep = max(deep, st["levels"] / max(st["evaluated"] + st["terminal"], 1))
         assert st["terminal"] > 0
+        act, win = eng.play()
         for g in range(G):
             opi, ovis, opol = agents[g].get_pi(roots[g], 0)
             np.testing.assert_array_equal(vis[g], ovis, err_msg="ply %d game %d" % (ply, g))
             np.testing.assert_array_equal(pol[g], opol)
             np.testing.assert_array_equal(pi[g], opi)
-            assert eng.get_rng_state(g)[1] == agents[g].rng.pos
-        act, win = eng.play()
-        roots = [roots[g] + (int(act[g]),) for g in range(G)]
-    assert deep > 40, deep   # mean levels per simulation: the chain is 81 long from simulation 81 on
+            oa = agents[g].rng.choice_p(opi)   # utils.get_action on the game's stream (eng.play did the same)
+            assert act[g] == oa
+            mt, pos, _, _ = eng.get_rng_state(g)
+            assert pos == agents[g].rng.pos
+            np.testing.assert_array_equal(mt, agents[g].rng.state_words())
+            roots[g] = roots[g] + (int(oa),)
+    # (terminal > 0 at every move, asserted above: with no winning line the only terminal leaf is the full board, so descents of
+    # 81 - ply levels did happen; the mean over all simulations of a move:)
+    assert deep > 30, deep
     eng.close()
 
 
