@@ -223,8 +223,6 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     ao::TreeParams& p = e->tp;
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
-    p.prefetch = 0;
-    if (const char* v = getenv("AO_TREE_PREFETCH")) p.prefetch = atoi(v) != 0;
     p.keep_max = c.node_cap - c.sims - 1;
     p.nchq = (((c.inplanes + 3) / 4) + 7) & ~7;  // worst case of the network's input layouts (net_plan)
     p.nchq_live = p.nchq;

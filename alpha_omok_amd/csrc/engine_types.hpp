@@ -57,7 +57,6 @@ enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
 //   Pos          the node's position (80 B)                                                  25 Ap
 struct TreeParams {
     int B, A, Ap, C, win_mark, G, cap, maxd, noise;
-    int prefetch;  // select_game touches the majority child's node record a level ahead (AO_TREE_PREFETCH=0 / 1; tree_device.hpp)
     int keep_max;  // most nodes a re-rooting keeps: cap - sims - 1, so the next move's expansions always fit
     int nchq;  // channel quads of the interleaved input batch: ceil(C/4) rounded up to even
     int nchq_live;  // quads the plane encoder writes: nchq, or ceil(C/4) when the padding quads are known to be zero

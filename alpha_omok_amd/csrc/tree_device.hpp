@@ -446,28 +446,9 @@ struct GameHdr {
     int is_active, done, target, arena, root_node, batch_row, mtpos;
 };
 
-// LDS landing area of select_game's speculative touch: one node record of a board with up to 64 * NCH edge slots
-template <int NCH>
-struct PfBytes { static constexpr int value = (25 * 64 * NCH + 80 + 127) & ~127; };
-
-// Requests node record `slot` (rows P N Q CH ACT W + position: 25 Ap + 80 bytes) with LDS-direct buffer loads, 1 KB per
-// instruction: nothing passes through registers and NOTHING READS the LDS copy -- the point is that the record's cache lines
-// are on their way (or in L2 / L1) when the next level asks for them.
-__device__ __forceinline__ void touch_record(const TreeParams& p, size_t slot, unsigned char* pf) {
-    const unsigned need = 25u * static_cast<unsigned>(p.Ap) + 80u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(node_rec(p, slot), 0, static_cast<int>(p.rec), 0x00020000);
-    const unsigned lane16 = static_cast<unsigned>(lane_id()) * 16u;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        if (k * 1024u < need && k * 1024u + lane16 < need)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(pf + k * 1024), 16, static_cast<int>(lane16),
-                                                     k * 1024, 0, 0);
-    }
-}
-
 template <int NCH>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr,
-                                            const GameHdr* hdr = nullptr, unsigned char* pf = nullptr /* LDS, PfBytes<NCH> */) {
+                                            const GameHdr* hdr = nullptr) {
     const int lane = lane_id();
     AO_TT(3);
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
@@ -543,31 +524,6 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             }
             tot = wave_sum_i(tot);
             AO_TT(5);
-            if (pf != nullptr && tot >= 8) {
-                // Speculation: a child that holds the MAJORITY of this node's visits is where the PUCT rule will most probably
-                // go (a trained policy sends simulation after simulation down one principal variation, and the launch lasts as
-                // long as its deepest descent: a chain of one memory round trip + ~250 instructions per level). Its record is
-                // requested now, before the fp64 arithmetic, the tie break and the pick; the next level's loads then find the
-                // lines in flight or in cache. A wrong guess costs one 2.5 KB read, the search itself reads nothing from the copy.
-                int key = -1;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int e = lane + 64 * c;
-                    const int k = (e < L) ? ((n[c] << 8) | e) : -1;
-                    key = k > key ? k : key;
-                }
-                key = wave_max_i(key);
-                if (key >= 0 && 2 * (key >> 8) > tot) {
-                    const int eb = key & 255;
-                    int cand = CH_UNVISITED;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int cv = read_lane(chv[c], eb & 63);
-                        if ((eb >> 6) == c) cand = cv;
-                    }
-                    if (cand >= 0) touch_record(p, node_slot(p, arena, g, cand), pf);
-                }
-            }
             // np.sqrt(total_n) (total_n is an exact integer): the device's correctly rounded double sqrt equals the host's for
             // every integer below 2^24 (tools/sqrt_exact.hip, checked exhaustively on the MI355X) -- computed, not looked up: the
             // table read depended on total_n and was one more memory round trip per level of the descent

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     __shared__ uint8_t s_ord[kGamesPerWG][256];
     __shared__ double s_prior[kGamesPerWG][256];
     __shared__ int16_t s_tab[kGamesPerWG][256];
-    __shared__ __attribute__((aligned(16))) unsigned char s_pf[kGamesPerWG][PfBytes<NCH>::value];   // select_game's speculative touch
     const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     const int g = blockIdx.x * kGamesPerWG + w;
     if (g >= p.G) return;
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w], &hdr);
     wsync();
     AO_TT(1);
-    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr, p.prefetch ? s_pf[w] : nullptr);
+    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr);
     AO_TT(2);
 }
 
