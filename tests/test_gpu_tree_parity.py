@@ -291,19 +291,21 @@ _DRAW_ORDER = [9, 43, 55, 14, 78, 32, 11, 23, 30, 3, 29, 47, 10, 17, 65, 20, 64,
                1, 67, 21, 58, 48, 54, 19, 71, 57, 36, 51, 16, 70, 26, 38, 41, 8, 52]
 
 
-def test_descents_longer_than_64_levels(oracle):
-    """A policy that puts 97 % on the next move of a full-board draw line and a value of 0 makes every simulation extend ONE
-    chain: the descent reaches 81 levels (the whole 9x9 board) and ends at a drawn terminal leaf. select_game keeps the path
-    in registers -- entry d in lane d & 63 of chunk d >> 6 -- and expand_backup_game walks it chunk by chunk: this is the
-    case with a second chunk. Three moves (the later ones search the inherited chain down to its drawn end), visits / priors / pi / stream
-    position against the oracle, bit for bit."""
-    B, S, G = 9, 200, 3
+@pytest.mark.parametrize("B,S,plies", [(9, 200, 3), (15, 320, 3)])
+def test_descents_longer_than_64_levels(oracle, B, S, plies):
+    """A policy that puts 97 % on the next move of one fixed line and a value of 0 makes every simulation extend ONE chain; with
+    win_mark above the board size (ZeroAgent.win_mark is a plain attribute in the reference; the oracle with such a mark was
+    checked against the reference itself) no line wins, so the chain runs until the board is full: descents of 81 levels on
+    9x9, 225 on 15x15, ending at a drawn terminal leaf. select_game keeps the path in registers -- entry d in lane d & 63 of
+    chunk d >> 6 -- and expand_backup_game walks it chunk by chunk: these are the cases with two and four chunks. Several moves
+    (the later ones search the inherited chain down to its end), visits / priors / pi / action / MT19937 state against the
+    oracle, bit for bit."""
+    G = 3
     A = B * B
-    # win_mark above the board size (ZeroAgent.win_mark is a plain attribute in the reference): no line wins, every game ends on
-    # the full board -- off-chain fives would otherwise end most descents early
-    eng = _engine(B, S, 5, games=G, noise=True, win_mark=10)
+    eng = _engine(B, S, 5, games=G, noise=True, win_mark=B + 1)
     run = HostEvalRunner(eng)
-    rank = {c: i for i, c in enumerate(_DRAW_ORDER)}
+    order = _DRAW_ORDER if B == 9 else np.random.RandomState(1).permutation(A).tolist()
+    rank = {c: i for i, c in enumerate(order)}
 
     def chain_eval(planes):
         occupied = (planes[:4].sum(axis=0) > 0).reshape(-1)   # planes 0..3: the two players' stones now and a move ago
@@ -317,14 +319,15 @@ def test_descents_longer_than_64_levels(oracle):
     for g in range(G):
         eng.seed(g, 500 + g)
         agents[g].seed(500 + g)
-        agents[g].set_win_mark(10)
+        agents[g].set_win_mark(B + 1)
     roots = [(0,)] * G
     deep = 0
-    for ply in range(3):
+    for ply in range(plies):
         pi, vis, pol = run.move(lambda g, sim, pl: chain_eval(pl), tau=np.zeros(G, np.int8))
         st = eng.search_stats()
         deep = max(deep, st["levels"] / max(st["evaluated"] + st["terminal"], 1))
-        assert st["terminal"] > 0
+        if ply > 0 and B == 9:
+            assert st["terminal"] > 0
         act, win = eng.play()
         for g in range(G):
             opi, ovis, opol = agents[g].get_pi(roots[g], 0)
@@ -337,9 +340,9 @@ def test_descents_longer_than_64_levels(oracle):
             assert pos == agents[g].rng.pos
             np.testing.assert_array_equal(mt, agents[g].rng.state_words())
             roots[g] = roots[g] + (int(oa),)
-    # (terminal > 0 at every move, asserted above: with no winning line the only terminal leaf is the full board, so descents of
-    # 81 - ply levels did happen; the mean over all simulations of a move:)
-    assert deep > 30, deep
+    # (9x9: terminal > 0 from the second move on, asserted above -- with no winning line the only terminal leaf is the full board,
+    # so descents of 81 - ply levels did happen. The mean over all simulations of a move; 15x15: chains of 100 - 200 levels)
+    assert deep > (30 if B == 9 else 100), deep
     eng.close()
 
 
