@@ -82,6 +82,8 @@ struct ao_engine {
     int node_cap_auto = 0;           // 1: node_cap was derived from the free HBM (ao_config.node_cap == -1)
     // HIP-event timing of the per-simulation tree kernel (k_expand_select) on the launch stream
     bool timing = false;
+    int timing_stride = 1;      // ao_tree_timing(enable = n > 1): every n-th launch is timed
+    unsigned timing_tick = 0;
     static constexpr int kRing = 256;
     std::vector<hipEvent_t> ev0, ev1;
     int ring_head = 0, ring_count = 0;
@@ -695,13 +697,14 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         if (ao::net_forward_il(net, net_in, rows, e->d_policy, e->d_value, e->stream, in_kind, fused ? (first_sim ? 3 : 2) : 7))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
         first_sim = false;
-        if (e->timing) {
+        const bool timed = e->timing && (e->timing_tick++ % static_cast<unsigned>(e->timing_stride) == 0u);   // (see ao_tree_timing)
+        if (timed) {
             if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);
             (void)hipEventRecord(e->ev0[e->ring_head], e->stream);
         }
         if (fused) ao::launch_step_board(p, step, rows, e->d_row + e->G, e->stream);
         else ao::launch_expand_select(p, e->stream);
-        if (e->timing) {
+        if (timed) {
             (void)hipEventRecord(e->ev1[e->ring_head], e->stream);
             e->ring_head = (e->ring_head + 1) % ao_engine::kRing;
             ++e->ring_count;
@@ -867,6 +870,8 @@ int ao_tree_timing(ao_engine* e, int enable, double* ms_total, int64_t* launches
     e->ms_total = 0.0;
     e->launches = 0;
     e->timing = enable != 0;
+    e->timing_stride = enable > 1 ? enable : 1;   // every n-th launch carries the event pair (their cost: see net_forward_il)
+    e->timing_tick = 0;
     return 0;
 }
 

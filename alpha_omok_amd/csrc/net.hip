@@ -73,7 +73,10 @@ struct ao_net {
     int ksplit_min = 48, ksplit_max = 64, ksplit_max2 = 0;
     int force_xt = 0, force_nch = 0;               // AO_XT / AO_NCH: tiling overrides for timing experiments (read at create)  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
-    bool timing = false;
+    bool timing = false;                           // THIS forward's launches are timed (see net_forward_il)
+    bool timing_on = false;                        // ao_net_conv_timing(enable): every `timing_stride`-th forward is timed
+    int timing_stride = 1;
+    unsigned timing_tick = 0;
     static constexpr int kRing = 512;
     std::vector<hipEvent_t> ev0, ev1;
     int ring_head = 0, ring_count = 0;
@@ -345,6 +348,9 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
+    // HIP-event timing of the conv launches: a pair of event records costs ~1 % of a 1.5 ms step when every launch carries one
+    // (tools/time_move_phases.py --events); with a stride only every n-th forward is timed -- the mean is the same estimate
+    n->timing = n->timing_on && (n->timing_tick++ % static_cast<unsigned>(n->timing_stride) == 0u);
     int group = 32, nchq = 0, nch = 1;
     bool heads_h16 = false;   // the separate head kernels read the split-fp16 layout
     net_plan(n, boards, &group, &nchq, nullptr);
@@ -1072,7 +1078,10 @@ int ao_net_conv_timing(ao_net* n, int enable, double* ms_total, int64_t* launche
     if (launches) *launches = n->launches;
     n->ms_total = 0.0;
     n->launches = 0;
-    n->timing = enable != 0;
+    n->timing_on = enable != 0;
+    n->timing_stride = enable > 1 ? enable : 1;
+    n->timing_tick = 0;
+    n->timing = false;
     return 0;
 }
 

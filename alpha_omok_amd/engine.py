@@ -118,9 +118,10 @@ class Net:
         return buf.value.decode(), f.value
 
     def conv_timing(self, enable=True):
-        """Returns (total ms, launches) of the trunk 3x3 conv kernel since the last call."""
+        """Returns (total ms, launches) of the TIMED trunk conv launches since the last call; enable = n > 1 times every
+        n-th forward only (an event pair per launch costs ~1 % of a 1.5 ms step)."""
         ms, cnt = C.c_double(0), C.c_int64(0)
-        self._check(self._L.ao_net_conv_timing(self._h, 1 if enable else 0, C.byref(ms), C.byref(cnt)),
+        self._check(self._L.ao_net_conv_timing(self._h, int(enable), C.byref(ms), C.byref(cnt)),
                     "ao_net_conv_timing")
         return ms.value, cnt.value
 
@@ -301,9 +302,10 @@ class Engine:
         return a.value, b.value
 
     def tree_timing(self, enable=True):
-        """(total ms, launches) of the per-simulation tree kernel (k_expand_select) since the last call."""
+        """(total ms, launches) of the TIMED per-simulation tree kernel launches (k_expand_select) since the last call;
+        enable = n > 1 times every n-th launch only."""
         ms, cnt = C.c_double(0), C.c_int64(0)
-        self._check(self._L.ao_tree_timing(self._h, 1 if enable else 0, C.byref(ms), C.byref(cnt)), "ao_tree_timing")
+        self._check(self._L.ao_tree_timing(self._h, int(enable), C.byref(ms), C.byref(cnt)), "ao_tree_timing")
         return ms.value, cnt.value
 
     def trim_stats(self):

@@ -129,8 +129,8 @@ int ao_get_root_children(ao_engine *e, int game, int32_t *host_action, double *h
 int ao_tree_nodes(ao_engine *e, int game, int64_t *expanded, int64_t *dict_entries);
 /* HIP-event timing of the per-simulation tree kernel of ao_search (k_expand_select: expansion + backup of one
  * simulation, selection + terminal test + plane encoding of the next -- agents.py:134-239 for every game), recorded
- * on the engine's launch stream. Returns the total and the number of launches since the previous call and
- * enables / disables the timing (bench.py's roofline_tree). */
+ * on the engine's launch stream. Returns the total and the number of TIMED launches since the previous call and
+ * enables / disables the timing (bench.py's roofline_tree); enable = n > 1: every n-th launch carries the event pair. */
 int ao_tree_timing(ao_engine *e, int enable, double *ms_total, int64_t *launches);
 /* Arena pressure, cumulative since ao_create. A game's arena holds node_cap expanded nodes; the tree kept across
  * moves (main.py:171 -> agents.py:84) grows by up to `sims` nodes per move when the visits keep following the played
@@ -199,8 +199,8 @@ int  ao_net_get_mode(const ao_net *n);
  * see ao_fp16_range_events. */
 enum { AO_NET_FP16_RANGE = 1 };
 int  ao_net_status(ao_net *n, void *stream, int32_t *flags, int clear);
-/* total device time (ms) and launch count of the dominant trunk kernel since the last call
- * (HIP events on the launch stream); used by bench.py's roofline. */
+/* total device time (ms) and count of the TIMED launches of the dominant trunk kernel since the last call
+ * (HIP events on the launch stream); used by bench.py's roofline. enable = n > 1: every n-th forward is timed. */
 int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launches);
 /* name and algorithmic FLOPs per launch (2*MAC, zero padding counted) of the kernel the timing
  * refers to, for a batch of `boards` positions. */

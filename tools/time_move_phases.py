@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--games", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--sims", type=int, default=400)
+ap.add_argument("--events", type=int, default=0, help="1: HIP-event timing of the trunk and tree launches on, as bench.py has it")
 a = ap.parse_args()
 torch.manual_seed(0)
 model = PVNet(4, 5, 128, 9).cuda().eval()
@@ -20,6 +21,8 @@ G = a.games
 eng = Engine(9, a.sims, 5, games=G, noise=True, device=0)
 eng.seed_all(np.arange(G, dtype=np.uint32))
 ply = np.zeros(G, np.int64)
+if a.events:
+    eng.tree_timing(True); net.conv_timing(True)
 nxt = G
 T = dict(search=0.0, stats=0.0, play=0.0, refill=0.0)
 def tick():
