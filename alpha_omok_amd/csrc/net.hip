@@ -71,6 +71,14 @@ struct ao_net {
     // correct, but no faster than k_layer16h at 1280 .. 2048 boards -- profiles/r4e_ksplit_medium_batches.txt -- so not planned
     // by default). AO_KSPLIT=lo,hi4,hi2 overrides (0,0,0 = off; 1,64,128 also plans KS = 2)
     int ksplit_min = 48, ksplit_max = 64, ksplit_max2 = 0;
+    // ... and below them, down to the per-board path, as k_row16hk (one workgroup per group x output row x cout pair, two per CU):
+    // search rate (tools/time_single_game.py --games n) +29 % at 48 games, +52 % at 64, +89 % at 96, +99 % at 128, +11 .. 19 % at
+    // 192 .. 512 against the per-board path / k_layer16h (profiles/r4w_row_kernel_small_batches.txt). AO_ROWK="lo,hi".
+    int rowk_min = 1, rowk_max = 47;
+    bool attr_r[16] = {};
+    // boards x cells up to which the per-board path is planned (boards of 4x4 .. 9x9, with k_row16hk behind it: 32 boards of 9x9 --
+    // it was 96 before that kernel; AO_PERBOARD_CELLS)
+    long perboard_cells = 2592;
     int force_xt = 0, force_nch = 0;               // AO_XT / AO_NCH: tiling overrides for timing experiments (read at create)  // dynamic-LDS attribute set for this net's device
     // timing of the dominant kernel (trunk conv launches)
     bool timing = false;                           // THIS forward's launches are timed (see net_forward_il)
@@ -200,7 +208,7 @@ static int pick_mode(const ao_net* n, int boards, int* nch_out) {
         const long cells = static_cast<long>(boards) * n->A;
         // (end of round 3, with the activations split once at staging and the fused per-game step: 9x9 per-board vs per-layer
         // 841 vs 653 move-decisions/s at 64 games, 983 vs 960 at 96, 1076 vs 1281 at 128; 15x15 equal at 24 games, 581 vs 816 at 36)
-        if (h16_supported(n)) mode = cells <= (n->B <= 9 ? 7776 : 5400) ? 3 : 5;
+        if (h16_supported(n)) mode = cells <= (n->B > 9 ? 5400 : n->B >= 4 ? n->perboard_cells : 7776) ? 3 : 5;
         else mode = cells <= 13000 ? 3 : (g16 >= 192 ? 2 : 4);
     }
     if (mode == 2 && (1 + 2 * n->nb > kMaxTrunkLayers)) mode = 4;
@@ -484,7 +492,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         // waves split the contraction (net_layer_ksplit.hpp); conv1 stays with k_layer16h. Never in mode 6 (one
         // arithmetic for every batch size).
         const int ks = (!layers_only(n) && n->B >= 4 && n->B <= 9 && groups >= n->ksplit_min) ? (groups <= n->ksplit_max ? 4 : groups <= n->ksplit_max2 ? 2 : 0) : 0;
-        const bool ksplit = ks != 0;
+        const bool rowk = !layers_only(n) && n->B >= 4 && n->B <= 9 && groups >= n->rowk_min && groups <= n->rowk_max;
+        const bool ksplit = ks != 0 || rowk;
         auto layer_k = [&](int l) -> int {
             LayerHArgs a;
             a.src = static_cast<const void*>((l & 1) ? n->act_x : n->act_t);
@@ -496,8 +505,27 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.ovf = n->d_status;
             a.res = !(l & 1) ? 1 : 0;
             a.nch = groups;
-            const dim3 grid((groups + 7) / 8 * 8 * ks), block(512);
+            const dim3 grid(rowk ? (groups + 7) / 8 * 8 * 4 * n->B : (groups + 7) / 8 * 8 * ks), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
+            if (rowk) {
+                switch (n->B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W: {                                                                                                          \
+        constexpr size_t lds_ = static_cast<size_t>(W) * 8 * 1024;                                                     \
+        if (!n->attr_r[W]) {                                                                                           \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_row16hk<W>),                               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            n->attr_r[W] = true;                                                                                       \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_row16hk<W>), grid, block, lds_, s, a);                                                   \
+    } break;
+                    AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+#undef AO_BW_CASE
+                    default: return n->fail("k_row16hk: board outside 4 .. 9");
+                }
+                if (n->timing) timer_end(n, idx, s);
+                return 0;
+            }
             switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W: {                                                                                                          \
@@ -770,6 +798,11 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     if (const char* v = getenv("AO_KSPLIT")) {   // "lo,hi4,hi2": groups that take k_layer16hk (timing experiments; "0,0,0" turns it off)
         int lo = 0, hi = 0, hi2 = 0;
         if (sscanf(v, "%d,%d,%d", &lo, &hi, &hi2) == 3) { n->ksplit_min = lo > 0 ? lo : 1 << 30; n->ksplit_max = hi; n->ksplit_max2 = hi2; }
+    }
+    if (const char* v = getenv("AO_PERBOARD_CELLS")) n->perboard_cells = atol(v);
+    if (const char* v = getenv("AO_ROWK")) {   // "lo,hi": groups that take k_row16hk ("0,-1" turns it off)
+        int lo = 0, hi = -1;
+        if (sscanf(v, "%d,%d", &lo, &hi) == 2) { n->rowk_min = lo; n->rowk_max = hi; }
     }
     if (const char* v = getenv("AO_TRUNK_FMT")) n->trunk_fmt = atoi(v) == 1 ? 1 : 0;
     // Default: two fp16 halves (4 bytes, ~22 significand bits). The 3-byte format (19 bits) is 2 % faster and costs ~4-8 x the
@@ -1104,6 +1137,11 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
         f = conv;
     } else if (group == 16 && mode == 4) {
         nm = "k_layer16<" + bw + "> (one 3x3 conv per launch, 16-board groups x row chunks, fp32 MFMA 16x16x4)";
+        f = conv;
+    } else if (group == 16 && mode == 5 && !layers_only(n) && n->B >= 4 && n->B <= 9 && (boards + 15) / 16 >= n->rowk_min &&
+               (boards + 15) / 16 <= n->rowk_max) {
+        nm = "k_row16hk<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): one workgroup per "
+             "16-board group x output row x cout pair, waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
     } else if (group == 16 && mode == 5 && !layers_only(n) && n->B >= 4 && n->B <= 9 && (boards + 15) / 16 >= n->ksplit_min &&
                (boards + 15) / 16 <= std::max(n->ksplit_max, n->ksplit_max2)) {

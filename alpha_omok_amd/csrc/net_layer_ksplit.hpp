@@ -312,4 +312,161 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
     if (peak > 65504.f) atomicOr(L.ovf, 1);
 }
 
+
+// k_row16hk: the same decomposition for SMALL and medium-small batches, where even four workgroups per group leave most of
+// the chip idle: workgroup (group, output row y, cout pair j) -- 36 workgroups per 9x9 group, all of a group on one XCD. Its
+// eight waves are k_layer16hk's (cout tile of the pair x 32-channel input block). ONE row buffer (72 KB on 9x9, so TWO
+// workgroups share a CU and one multiplies while the other waits for its row): for each of the three input rows y-1, y, y+1 it
+// stages the row and the wave's six weight fragments of that tap row (3 taps x {high, low}), waits, multiplies; the finished
+// partial tiles go through the same buffer in the 4-way exchange of k_layer16hk. No window, no pipeline inside the workgroup:
+// what it buys is parallelism (16 groups: 576 workgroups, two per CU, instead of k_layer16hk's 64 or k_layer16h's 144). Per
+// accumulator the order of the MFMAs (input rows y-1, y, y+1; inside a row: cell, product, tap column) and the order of the
+// exchange (input blocks 0 .. 3) are k_layer16hk's: the results are the same bits.
+template <int BW>
+__global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
+    constexpr int KS = 4, TW = 2;
+    constexpr int NC32 = 4, NCI = 4, NT = 8;
+    constexpr int A = BW * BW;
+    constexpr int NFR = BW * NCI * 2;
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];   // [NFR][64]
+    const int groups = a.nch;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, rr = bid >> 3;
+    const int j = rr % KS, y = (rr / KS) % BW, grp = (rr / (KS * BW)) * 8 + xcd;
+    if (grp >= groups) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int t_loc = w % TW, kp = w / TW;
+    const int tile = j * TW + t_loc;
+    const int kq = lane >> 4, b = lane & 15;
+    const int lane16 = lane * 16;
+    const int out_voff = (((tile & 1) * 2 + (kq >> 1)) * 16 + b) * 16 + (kq & 1) * 8;
+    const TrunkHLayer& L = a.layer;
+    const bool RES = a.res != 0;
+    const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+    const uint4* src = static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
+    uint4* dst = a.dst + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(src, static_cast<unsigned>(A) * NCI * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rs_dst = make_rsrc(dst, static_cast<unsigned>(A) * NC32 * 2u * 1024u);
+    constexpr int NOWN = (BW + KS - 1) / KS;
+    auto stage_row = [&](int yy) {   // (the wave's share of the row's 8 * BW fragments: see k_layer16hk)
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+#pragma unroll
+            for (int o = 0; o < NOWN; ++o) {
+                const int i = kp + KS * o;
+                if (i < BW) {
+                    const int f = (t_loc + TW * q) * BW + i;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(s_x + f * 64), 16, lane16,
+                                                             (yy * NFR + f) * 1024, 0, AO_AUX_STAGE);
+                }
+            }
+        }
+    };
+    f32x4 acc[BW];
+#pragma unroll
+    for (int i = 0; i < BW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto ldx = [&](int xi, int half) -> half8 { return __builtin_bit_cast(half8, s_x[((xi * NCI + kp) * 2 + half) * 64 + lane]); };
+    // one tap row: stage input row y - 1 + DY, fetch the wave's six weight fragments of that tap row, wait, multiply
+    auto phase = [&](auto dy_tag, bool first) {
+        constexpr int DY = decltype(dy_tag)::value;
+        const int yy = y - 1 + DY;
+        if (yy < 0 || yy >= BW) return;   // (uniform)
+        if (!first) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everybody is done reading the previous row
+        stage_row(yy);
+        half8 W[2][3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ub = (((DY * 3 + dx) * NCI + kp) * NT + tile) * 1024;
+            W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
+            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {   // (a use the wait-count pass can see: k_layer16hk)
+            asm volatile("" ::"v"(W[0][dx]));
+            asm volatile("" ::"v"(W[1][dx]));
+        }
+        half8 xh = ldx(0, 0), xl = ldx(0, 1);
+#pragma unroll
+        for (int xi = 0; xi < BW; ++xi) {
+            half8 nh = xh, nl = xl;
+            if (xi + 1 < BW) {
+                nh = ldx(xi + 1, 0);
+                nl = ldx(xi + 1, 1);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int i = xi - dx + 1;
+                    if (i < 0 || i >= BW) continue;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(W[pr == 1 ? 1 : 0][dx], pr == 2 ? xl : xh, acc[i], 0, 0, 0);
+                }
+            }
+            xh = nh;
+            xl = nl;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    phase(std::integral_constant<int, 0>{}, true);
+    phase(std::integral_constant<int, 1>{}, y == 0);
+    phase(std::integral_constant<int, 2>{}, false);
+    // the residual of the owned cells: requested before the exchange's barriers
+    half4 rh[NOWN], rl[NOWN];
+    if (RES) {
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int i = kp + KS * o < BW ? kp + KS * o : BW - 1;
+            const int ob = (((y * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+            rh[o] = buf_ld_h4(rs_dst, out_voff, ob);
+            rl[o] = buf_ld_h4(rs_dst, out_voff, ob + 1024);
+        }
+    }
+    // exchange through the row buffer: every wave parks its nine partial tiles, the owner of a cell adds the four partners' in
+    // the order of the input blocks (= k_layer16hk's finish)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the last row is read
+#pragma unroll
+    for (int i = 0; i < BW; ++i) s_x[(w * BW + i) * 64 + lane] = __builtin_bit_cast(uint4, acc[i]);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (RES) {
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            asm volatile("" ::"v"(rh[o]));
+            asm volatile("" ::"v"(rl[o]));
+        }
+    }
+    float peak = 0.f;
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int i = kp + KS * o;
+        if (i >= BW) continue;
+        f32x4 p[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) p[q] = __builtin_bit_cast(f32x4, s_x[((t_loc + TW * q) * BW + i) * 64 + lane]);
+        f32x4 c = p[0] + p[1];
+#pragma unroll
+        for (int q = 2; q < KS; ++q) c = c + p[q];
+        float f[4] = {fmaf(c[0], sc.x, sh.x), fmaf(c[1], sc.y, sh.y), fmaf(c[2], sc.z, sh.z), fmaf(c[3], sc.w, sh.w)};
+        if (RES) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] += static_cast<float>(rh[o][r]) + static_cast<float>(rl[o][r]);
+        }
+        peak = fmaxf(fmaxf(peak, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
+        half4 hh, hl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = fminf(fmaxf(f[r], 0.f), 65504.f);
+            hh[r] = static_cast<_Float16>(v);
+            hl[r] = static_cast<_Float16>(v - static_cast<float>(hh[r]));
+        }
+        const int ob = (((y * BW + i) * NC32 + (tile >> 1)) * 2) * 1024;
+        buf_st_h4(hh, rs_dst, out_voff, ob);
+        buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
+    }
+    if (peak > 65504.f) atomicOr(L.ovf, 1);
+}
+
 }  // namespace ao

@@ -53,7 +53,10 @@ def test_plan_kernel_follows_batch_size_and_input_kind():
     assert plan_kernel(4, 5, 128, 9, 1024, in_kind=2)[0].startswith("k_layer16hk<9, 4>")    # medium batch: cout-pair split
     assert plan_kernel(4, 5, 128, 9, 768, in_kind=2)[0].startswith("k_layer16hk<9, 4>")
     assert plan_kernel(4, 5, 128, 9, 2048, in_kind=2)[0].startswith("k_layer16h<9>")         # (the two-workgroup form is not planned by default)
-    assert plan_kernel(4, 5, 128, 9, 640, in_kind=2)[0].startswith("k_layer16h<9>")
+    assert plan_kernel(4, 5, 128, 9, 640, in_kind=2)[0].startswith("k_row16hk<9>")            # small batch: one workgroup per group x row x cout pair
+    assert plan_kernel(4, 5, 128, 9, 48, in_kind=2)[0].startswith("k_row16hk<9>")
+    assert plan_kernel(4, 5, 128, 9, 32, in_kind=1)[0].startswith("k_conv_cells_h<9, 8>")
+    assert plan_kernel(4, 5, 128, 9, 640, in_kind=2, trunk_mode=6)[0].startswith("k_layer16h<9>")
     assert plan_kernel(4, 5, 128, 9, 2560, in_kind=2)[0].startswith("k_layer16h<9>")
     assert plan_kernel(4, 5, 128, 9, 1024, in_kind=2, trunk_mode=6)[0].startswith("k_layer16h<9>")   # one arithmetic for every batch size
     assert plan_kernel(4, 5, 64, 9, 4096, in_kind=1)[0].startswith("k_trunk16<9>")

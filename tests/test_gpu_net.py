@@ -227,6 +227,80 @@ def test_medium_batch_ksplit_layer_kernel(nb, B, batch, seed, monkeypatch):
     net.close()
 
 
+@pytest.mark.parametrize("nb,B,batch,seed", [(4, 9, 128, 1), (4, 9, 100, 2), (10, 9, 333, 3), (2, 9, 750, 4), (3, 7, 200, 5), (2, 5, 512, 6),
+                                             (1, 4, 200, 7), (2, 8, 48, 8), (2, 6, 640, 9), (4, 9, 33, 10)])
+def test_small_batch_row_kernel(nb, B, batch, seed, monkeypatch):
+    """Small and medium-small batches (from 33 boards of 9x9 up to 47 groups of 16) run their trunk convs as k_row16hk: one
+    workgroup per (group, output row, cout pair), two per CU, the waves splitting the contraction as in k_layer16hk
+    (net_layer_ksplit.hpp). Same arithmetic in the same order as k_layer16hk: BIT-identical to a network whose every group count
+    is planned as k_layer16hk; against the per-layer kernel (mode 6), the fp32-MFMA kernels (mode 4) and torch fp32; twice,
+    bit-identical; ragged last group; and a 400-free search through it (ao_search: tree kernels + bit planes) against the
+    step-wise protocol with the same network."""
+    import torch
+    from alpha_omok_amd.engine import Engine
+    from alpha_omok_amd.pvnet import PVNet
+    sd = pvnet_weights.make_state_dict(nb, 5, 128, B, seed)
+    ref = PVNet(nb, 5, 128, B)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ref.eval()
+    rs = np.random.RandomState(batch + B)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    x[:, 4] = (rs.rand(batch, 1, 1) < 0.5).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    net = ref.to_native(0)
+    monkeypatch.setenv("AO_ROWK", "0,-1")
+    monkeypatch.setenv("AO_KSPLIT", "1,4096,0")
+    net_k = ref.to_native(0)
+    monkeypatch.delenv("AO_ROWK")
+    monkeypatch.delenv("AO_KSPLIT")
+    assert net.dominant_kernel(batch)[0].startswith("k_row16hk<%d>" % B), net.dominant_kernel(batch)[0]
+    assert net_k.dominant_kernel(batch)[0].startswith("k_layer16hk<%d, 4>" % B), net_k.dominant_kernel(batch)[0]
+    outs = {}
+    for mode in (5, 6, 4, 5):
+        net.set_mode(mode)
+        p, v = net(xt)
+        torch.cuda.synchronize()
+        p, v = p.cpu().numpy(), v.cpu().numpy()
+        assert np.isfinite(p).all() and np.isfinite(v).all() and net.status() == 0
+        if mode in outs:
+            np.testing.assert_array_equal(outs[mode][0], p)
+            np.testing.assert_array_equal(outs[mode][1], v)
+        outs[mode] = (p, v)
+    pk, vk = net_k(xt)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(outs[5][0], pk.cpu().numpy())
+    np.testing.assert_array_equal(outs[5][1], vk.cpu().numpy())
+    for m in (6, 4):
+        assert np.abs(outs[5][0] - outs[m][0]).max() < (1.5e-4 if nb > 6 else 2e-5), m
+        assert np.abs(outs[5][1] - outs[m][1]).max() < (1.5e-4 if nb > 6 else 2e-5), m
+    idx = rs.choice(batch, min(batch, 96), replace=False)
+    idx[:4] = [0, 15, batch - 1, batch - (batch % 16 or 16)]
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x[idx]))
+    assert np.abs(outs[5][0][idx] - rp.numpy()).max() < TOL and np.abs(outs[5][1][idx] - rv.numpy()).max() < TOL
+    net_k.close()
+    if B >= 5 and batch <= 200:
+        # a search with that many games: the fused loop (bit planes -> conv1 -> k_row16hk x 2 nb -> head kernels -> k_expand_select)
+        # against the step-wise protocol with the same network
+        net.set_mode(0)
+        S, G = 10, batch
+        a, b2 = Engine(B, S, 5, games=G, noise=True), Engine(B, S, 5, games=G, noise=True)
+        seeds = np.arange(G, dtype=np.uint32) + 3
+        a.seed_all(seeds); b2.seed_all(seeds)
+        pi, vis, pol = a.search(net, tau=1)
+        planes_t = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
+        b2.begin_move()
+        while b2.sims_left() > 0:
+            b2.collect_leaves(planes_t.data_ptr()); b2.sync()
+            pp, vv = net(planes_t); torch.cuda.synchronize()
+            b2.apply_evals(pp.data_ptr(), vv.data_ptr())
+        pi2, vis2, pol2 = b2.end_move(np.ones(G, np.int8))
+        np.testing.assert_array_equal(vis, vis2)
+        np.testing.assert_array_equal(pol, pol2)
+        a.close(); b2.close()
+    net.close()
+
+
 @pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 256, 40), (1, 5, 192, 700), (2, 15, 160, 24), (3, 9, 224, 1024), (1, 3, 256, 5)])
 def test_wide_networks_run_on_the_fp32_layer_kernels(nb, B, planes, batch):
     """model.PVNet takes any `planes` (model.py:76-85). 160 .. 256 planes (multiples of 32) run natively on the row-chunked
