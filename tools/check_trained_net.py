@@ -96,6 +96,9 @@ def main():
     fw["resident_fmt1_3byte"] = run(5, fmt=1)
     fw["per_layer_split_fp16"] = run(6)
     fw["per_layer_split_fp16_1024_boards"] = run(6, boards=1024)
+    fw["ksplit_1024_boards"] = run(0, boards=1024)          # mode 0 = the planner: k_layer16hk at 48 .. 64 groups
+    fw["row_kernel_512_boards"] = run(0, boards=512)        # ... k_row16hk below (33 boards .. 47 groups)
+    fw["row_kernel_100_boards"] = run(0, boards=100)
     fw["per_board_64_boards"] = run(3, boards=64)
     fw["fp32_mfma_trunk"] = run(2)
     with torch.no_grad():
