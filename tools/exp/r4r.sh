@@ -1,3 +1,4 @@
+# (A/B script of a variant that was measured and NOT kept: AO_TREE_PREFETCH is not in the tree -- profiles/r4r_tree_touch_ab.txt)
 # round 4: select_game touching the majority child's node record a level ahead (LDS-direct, nothing reads the copy): parity, then the
 # tree kernel with the trained and the random-init network and one game alone, AO_TREE_PREFETCH=0 / 1 back to back, twice
 AO_TREE_PREFETCH=1 python -m pytest tests/test_gpu_tree_parity.py tests/test_gpu_dropin.py tests/test_gpu_edges.py tests/test_gpu_soak.py -x -q > gpurun_out/r4r_pytest.log 2>&1; tail -3 gpurun_out/r4r_pytest.log

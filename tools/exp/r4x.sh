@@ -1,3 +1,4 @@
+# (A/B script of a variant that was measured and NOT kept: AO_ROWK_HALVES is not in the tree -- profiles/r4x_row_kernel_column_halves.txt)
 # round 4: k_row16hk with the row's cells on TWO workgroups (AO_ROWK_HALVES=2: 48 KB of LDS, three workgroups per CU) against one (72 KB, two per CU):
 # correctness (same bits as k_layer16hk), the forward by batch size, extended group ranges
 AO_ROWK_HALVES=2 timeout 300 python tools/exp/r4v_check.py 2>&1 | grep -v amdgpu | cut -c1-110

@@ -1,3 +1,4 @@
+# (A/B script of a variant that was measured and NOT kept: k_layer16h2 / AO_XT=2,3 are not in the tree -- profiles/r4y_layer16h_15x15_narrow_tiles.txt)
 # round 4: 15x15 per-layer path with NARROW column tiles and two workgroups per CU (k_layer16h2, AO_XT=2 / 3) against XT=4 (256 workgroups, one per CU):
 # correctness against torch fp32 first, then the forward (1024 boards, 10 blocks) and the bench of configs[4]'s per-GPU shape
 python - <<'PY'
