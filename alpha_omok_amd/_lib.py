@@ -69,6 +69,10 @@ SYMBOLS = {
     "ao_host_threads": (C.c_int, []),
     "ao_fp16_range_events": (C.c_int, [_vp, _i64p, _i64p]),
     "ao_search_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "ao_set_row_cap": (C.c_int, [_vp, C.c_int32]),
+    "ao_row_stats": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "ao_set_eval_log": (C.c_int, [_vp, _i32p, C.c_int32, _vp, C.c_int64]),
+    "ao_eval_log_count": (C.c_int, [_vp]),
     "ao_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P(_vp)]),
     "ao_net_destroy": (None, [_vp]),
     "ao_net_last_error": (C.c_char_p, [_vp]),

@@ -13,8 +13,9 @@ CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libomok_hip.so")
 SOURCES = ["tree_kernels.hip", "step_kernels.hip", "engine.hip", "net.hip", "replay.hip", "rollout.hip"]
-HEADERS = ["engine_types.hpp", "host_rng.hpp", "tree_device.hpp", "net_device.hpp", "net_common.hpp", "net_trunk_f32.hpp",
-           "net_trunk_h16.hpp", "net_small.hpp", os.path.join(INC, "omok_hip.h")]
+# every header under csrc/ (listed from the directory, so a new kernel header can never be missing from the staleness
+# check or from source_hash() -- round 4 shipped net_layer_ksplit.hpp outside this list) + the C ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(INC, "omok_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-I", INC]
 

@@ -34,7 +34,9 @@ void launch_walk(const TreeParams& p, int count, const int32_t* games, const int
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s);
 // net.hip
 int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value,
-                   hipStream_t s, int in_kind, int parts);
+                   hipStream_t s, int in_kind, int parts, const unsigned* live, unsigned row_cap);
+void launch_eval_log(const int32_t* games, int n, const int32_t* row_of_game, const float* policy, const float* value, int A,
+                     float* out, const int32_t* sims_done, const int32_t* leaf_status, int what, hipStream_t s);
 int net_step_params(ao_net* n, int boards, float* policy, float* value, StepNet* out);
 void net_fp16_fallback_begin(ao_net* n);
 int net_fp16_fallback_end(ao_net* n);
@@ -60,8 +62,18 @@ struct ao_engine {
     std::vector<int32_t> h_walk;     // staging of ao_set_root(s): [G][A] moves + games, counts, prev_known, status
     float* d_policy = nullptr; float* d_value = nullptr;  // native-net outputs [Gp][A], [Gp]
     uint8_t* d_planes_u8 = nullptr;                       // bit planes [Gp][u8_row] (input of the split-fp16 kernels)
-    int32_t* d_row = nullptr;                             // [2G] batch row of each game in ao_search (active games packed), then the game of each row
+    int32_t* d_row = nullptr;                             // [2G] batch row of each game in ao_search (active games packed, or handed out per simulation by the tree kernel), then the game of each row
     std::vector<int32_t> h_row;
+    // rows handed out per simulation (engine_types.hpp TreeParams::live): one counter word per launch of a move, zeroed at the start
+    // of the move (and when the ring wraps); row_cap = rows one simulation may take (0: as many as there are active games)
+    static constexpr int kLive = 2048;
+    unsigned* d_live = nullptr;
+    unsigned* h_live = nullptr;                           // pinned [kLive]
+    int row_cap = 0;
+    double ask_frac = 1.0;                                // rows asked for per simulation of a game in the last over-subscribed move (1 - terminal share)
+    int64_t rs_launches = 0, rs_rows_live = 0, rs_rows_launched = 0, rs_waits = 0;   // ao_row_stats
+    // ao_set_eval_log: what the network returned to the listed games, per simulation of the current ao_search
+    int32_t* d_log_games = nullptr; int log_n = 0; float* log_dev = nullptr; int64_t log_cap = 0; int64_t log_sim = 0;
     size_t il_bytes = 0; int il_group_zeroed = -1, il_nchq_zeroed = -1;  // layout for which batch_il's padding is zero
     // host mirrors
     std::vector<std::vector<int32_t>> moves;
@@ -155,6 +167,7 @@ void ao_destroy(ao_engine* e) {
     if (e->h_noise) hipHostFree(e->h_noise);
     if (e->h_out) hipHostFree(e->h_out);
     if (e->h_i32) hipHostFree(e->h_i32);
+    if (e->h_live) hipHostFree(e->h_live);
     for (auto ev : e->ev0) (void)hipEventDestroy(ev);
     for (auto ev : e->ev1) (void)hipEventDestroy(ev);
     if (e->own_stream) hipStreamDestroy(e->own_stream);
@@ -255,7 +268,12 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.u8_row = A <= 128 ? 128 : 256;
     if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, 2 * static_cast<size_t>(G))) return 1;
     if (dev_alloc(e, &e->d_mt_backup, static_cast<size_t>(G) * 624) || dev_alloc(e, &e->d_pos_backup, G)) return 1;
+    if (dev_alloc(e, &e->d_live, ao_engine::kLive) || dev_alloc(e, &e->d_log_games, G)) return 1;
+    AO_HIP(e, hipMemsetAsync(e->d_row, 0, sizeof(int32_t) * 2 * G, e->stream));
+    AO_HIP(e, hipMemsetAsync(e->d_live, 0, sizeof(unsigned) * ao_engine::kLive, e->stream));
     p.row_of_game = nullptr;
+    p.live = nullptr;
+    p.row_cap = 0;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
     p.batch_u8 = nullptr;
     e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
@@ -278,6 +296,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_noise), sizeof(double) * G * Ap, hipHostMallocDefault));
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), sizeof(double) * 3 * G * A, hipHostMallocDefault));
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_i32), sizeof(int32_t) * 4 * G, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_live), sizeof(unsigned) * ao_engine::kLive, hipHostMallocDefault));
     std::memset(e->h_noise, 0, sizeof(double) * G * Ap);
 
     e->moves.assign(G, {});
@@ -650,9 +669,16 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     }
     // the network announces the interleaved input layout it wants for a batch of G boards
     if (ao_begin_move(e, active)) return 1;
-    // The network runs on the ACTIVE games only: they are packed to the front of the evaluation batch (row_of_game), so
-    // a move in which a third of the slots still plays -- the tail of main.self_play(n), one side of evaluate_batched,
-    // an uneven shard -- costs a third of the network time, and may take another kernel (net_plan for that many boards).
+    // The network runs on the ACTIVE games only. Two regimes (engine_types.hpp, TreeParams::live):
+    //  * a handful of games on the per-board path with the fused per-game step: the host packs the active games to the front of
+    //    the evaluation batch once per move (row_of_game / game_of_row);
+    //  * everything else (round 5): the tree kernel hands out the rows PER SIMULATION -- a game whose new leaf needs the network takes
+    //    the next row, a terminal leaf takes none (agents.py:171-178,216-221: the reference evaluates it and throws the result
+    //    away) -- and counts them in one device word per launch that the trunk kernels read: groups without a live row exit at
+    //    once, no host read-back in the loop. With a trained network 11 - 19 % of all leaves are terminal. ao_set_row_cap bounds
+    //    the rows of one simulation BELOW the number of games (over-subscription: 5120 games on the 4096 rows = 256 groups the
+    //    resident trunk fills the chip with); a leaf that finds the batch full waits for the next launch (LS_WAIT), the loop below
+    //    runs until every game has its simulations. A game's search is strictly sequential in every regime: same bits.
     int rows = 0;
     e->h_row.assign(2 * static_cast<size_t>(e->G), 0);
     for (int g = 0; g < e->G; ++g)
@@ -661,9 +687,10 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
             e->h_row[g] = rows++;
         }
     if (rows == 0) return ao_end_move(e, tau, pi, visit, policy);
-    AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * 2 * e->G, hipMemcpyHostToDevice, e->stream));
+    static const bool static_rows = getenv("AO_STATIC_ROWS") != nullptr;   // developer switch: the per-move packing of rounds 3 - 4 everywhere
+    const int cap_rows = (!static_rows && e->row_cap > 0 && e->row_cap < rows) ? e->row_cap : rows;
     int in_kind = 1;
-    ao::net_plan(net, rows, &e->tp.il_group, &e->tp.nchq, &in_kind);
+    ao::net_plan(net, cap_rows, &e->tp.il_group, &e->tp.nchq, &in_kind);
     // The padding channels of the fp32 input batch (planes 5..31 of a 32-channel slab) are zero and stay zero: the
     // encoder only writes the quads that hold planes (16 B per lane at a 2 KB stride are partial-line writes --
     // rocprof showed 152 MB of HBM writes per launch for a 42 MB batch). A change of layout re-zeroes the buffer.
@@ -691,19 +718,92 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // A few games (the per-board network path): heads, tree step and the next leaf's conv1 are ONE launch per game
     // (k_step_board), the network is asked for the residual blocks alone -- 9 launches per simulation instead of 11.
     ao::StepNet step{};
-    const bool fused = ao::net_step_params(net, rows, e->d_policy, e->d_value, &step) != 0;
+    const bool fused = cap_rows == rows && ao::net_step_params(net, rows, e->d_policy, e->d_value, &step) != 0;
+    static const bool force_dynamic = getenv("AO_DYNAMIC_ROWS") != nullptr;   // developer switch: hand out rows per simulation without ao_set_row_cap
+    // (opt-in: the hand-out costs one atomic per workgroup on one word, ~11 ns each -- 10 us on top of a 20 us tree kernel when 4096
+    // descents of equal depth arrive together, profiles/r5a_row_alloc_atomics.txt; it pays when leaves are terminal)
+    const bool dynamic = !fused && !static_rows && (e->row_cap > 0 || force_dynamic);
+    if (dynamic) {
+        AO_HIP(e, hipMemsetAsync(e->d_live, 0, sizeof(unsigned) * ao_engine::kLive, e->stream));
+        p.row_cap = static_cast<unsigned>(cap_rows);
+    } else {
+        AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * 2 * e->G, hipMemcpyHostToDevice, e->stream));
+    }
+    int launch = 0, harvested = 0;   // selection launches of this move so far (launch i counts its rows in slot i % kLive); slots already summed up
+    // Over-subscription (more active games than rows per simulation). Every launch a window of the game indices sits out, sized so
+    // that the games that do descend ask for about cap_rows rows -- a share `ask_frac` of them does (the rest ends at terminal
+    // leaves), measured over the previous move of this engine, less three standard deviations of that binomial; the window moves on
+    // by its own length per launch (see select_game). `unfinished` = games that still need simulations.
+    const bool oversub = dynamic && cap_rows < rows;
+    const int64_t rows_live_before = e->rs_rows_live;
+    int64_t sims_wanted = 0;
+    for (int g = 0; g < e->G; ++g)
+        if (e->active[g]) sims_wanted += (e->status[g] == AO_ROOT_FRESH) ? e->S + 1 : e->S;
+    unsigned sit_idx = 0;
+    auto plan_sit = [&](int unfinished) {
+        sit_idx = 0;
+        if (!oversub || unfinished <= 0) return;
+        const double f = std::min(1.0, std::max(0.5, e->ask_frac));
+        const double slack = 3.0 * std::sqrt(static_cast<double>(cap_rows) * (1.0 - f));
+        const double askers = std::min<double>(unfinished, std::floor((cap_rows - slack) / f));
+        sit_idx = static_cast<unsigned>(std::lround((unfinished - askers) * e->G / static_cast<double>(unfinished)));
+        if (sit_idx >= static_cast<unsigned>(e->G)) sit_idx = static_cast<unsigned>(e->G) - 1u;
+    };
+    auto set_sit = [&](int i) {
+        p.sit_n = sit_idx;
+        p.sit_off = sit_idx ? static_cast<unsigned>((static_cast<uint64_t>(i) * sit_idx) % static_cast<uint64_t>(e->G)) : 0u;
+    };
+    plan_sit(rows);
+    auto slot = [&](int i) -> unsigned* { return dynamic ? e->d_live + (i % ao_engine::kLive) : nullptr; };
+    // sums up the row counters of the selection launches [harvested, upto) -- each of them was followed by a network launch
+    auto harvest_rows = [&](int upto) -> int {
+        if (!dynamic || upto <= harvested) return 0;
+        AO_HIP(e, hipMemcpyAsync(e->h_live, e->d_live, sizeof(unsigned) * ao_engine::kLive, hipMemcpyDeviceToHost, e->stream));
+        AO_HIP(e, hipStreamSynchronize(e->stream));
+        for (int i = harvested; i < upto; ++i) {
+            const int64_t want = e->h_live[i % ao_engine::kLive];
+            e->rs_rows_live += std::min<int64_t>(want, cap_rows);
+            e->rs_waits += std::max<int64_t>(want - cap_rows, 0);
+            e->rs_rows_launched += cap_rows;
+            ++e->rs_launches;
+        }
+        harvested = upto;
+        return 0;
+    };
+    // what: 1 = policy + value, 2 = simulation count + leaf status (the fused step computes the heads AND moves on to the next leaf
+    // in one kernel: the two halves of a record are taken on either side of it)
+    auto log_evals = [&](int what) {
+        if (e->log_n > 0 && (e->log_sim + 1) * e->log_n * (e->A + 3) <= e->log_cap) {
+            ao::launch_eval_log(e->d_log_games, e->log_n, e->d_row, e->d_policy, e->d_value, e->A,
+                                e->log_dev + e->log_sim * e->log_n * (e->A + 3), e->tp.sims_done, e->tp.leaf_status, what, e->stream);
+            if (what & 1) ++e->log_sim;
+        }
+    };
     bool first_sim = true;
     auto one_sim = [&]() -> int {
-        if (ao::net_forward_il(net, net_in, rows, e->d_policy, e->d_value, e->stream, in_kind, fused ? (first_sim ? 3 : 2) : 7))
+        if (ao::net_forward_il(net, net_in, cap_rows, e->d_policy, e->d_value, e->stream, in_kind, fused ? (first_sim ? 3 : 2) : 7,
+                               slot(launch), static_cast<unsigned>(cap_rows)))
             return e->fail(std::string("network forward failed: ") + ao_net_last_error(net));
         first_sim = false;
+        log_evals(fused ? 2 : 3);   // (before the tree kernel moves on / hands out the next simulation's rows)
         const bool timed = e->timing && (e->timing_tick++ % static_cast<unsigned>(e->timing_stride) == 0u);   // (see ao_tree_timing)
         if (timed) {
             if (e->ring_count == ao_engine::kRing) tree_harvest(e, ao_engine::kRing / 2);
             (void)hipEventRecord(e->ev0[e->ring_head], e->stream);
         }
-        if (fused) ao::launch_step_board(p, step, rows, e->d_row + e->G, e->stream);
-        else ao::launch_expand_select(p, e->stream);
+        ++launch;
+        if (dynamic && launch % ao_engine::kLive == 0) {   // the counter ring wraps (more than kLive launches in one move): sum it up, zero it
+            if (harvest_rows(launch)) return 1;
+            AO_HIP(e, hipMemsetAsync(e->d_live, 0, sizeof(unsigned) * ao_engine::kLive, e->stream));
+        }
+        if (fused) {
+            ao::launch_step_board(p, step, rows, e->d_row + e->G, e->stream);
+            log_evals(1);              // (the heads of this simulation ran inside the step kernel)
+        } else {
+            p.live = slot(launch);
+            set_sit(launch);
+            ao::launch_expand_select(p, e->stream);
+        }
         if (timed) {
             (void)hipEventRecord(e->ev1[e->ring_head], e->stream);
             e->ring_head = (e->ring_head + 1) % ao_engine::kRing;
@@ -713,6 +813,8 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         return 0;
     };
     if (e->sims_left > 0) {
+        p.live = slot(0);
+        set_sit(0);
         ao::launch_select(p, e->stream);
         AO_HIP(e, hipGetLastError());
     }
@@ -727,6 +829,49 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         --e->sims_left;
     }
     if (rc) return rc;
+    if (oversub && sit_idx > 0) {
+        // a game sits out sit_idx / G of the launches: that many more launches before anyone can be done
+        const int planned = static_cast<int>(std::ceil(static_cast<double>(lt_sims) * e->G / (e->G - sit_idx))) - lt_sims;
+        for (int k = 0; k < planned - 1 && rc == 0; ++k) rc = one_sim();
+        if (rc) return rc;
+    }
+    if (oversub) {
+        // over-subscribed: leaves that found their simulation's batch full were expanded one launch later, so some games are
+        // short of their simulations. The counters say by how much; max(largest deficit, all deficits / rows per launch)
+        // is a lower bound of the launches still needed -- run them, look again.
+        const int G = e->G;
+        int32_t* h_done = e->h_i32;
+        int32_t* h_target = e->h_i32 + G;
+        int32_t* h_err = e->h_i32 + 2 * G;
+        int64_t last_sum = -1;
+        for (int round = 0; round < 4 * (e->S + 2); ++round) {
+            AO_HIP(e, hipMemcpyAsync(h_done, e->tp.sims_done, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+            AO_HIP(e, hipMemcpyAsync(h_target, e->tp.sims_target, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+            AO_HIP(e, hipMemcpyAsync(h_err, e->tp.err, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
+            AO_HIP(e, hipStreamSynchronize(e->stream));
+            int64_t sum = 0;
+            int mx = 0;
+            bool bad = false;
+            for (int g = 0; g < G; ++g) {
+                if (!e->active[g]) continue;
+                bad = bad || h_err[g] != 0;
+                const int d = h_target[g] - h_done[g];
+                if (d > 0) { sum += d; mx = std::max(mx, d); }
+            }
+            if (mx == 0 || bad || sum == last_sum) break;   // done / a per-game error (reported by ao_end_move) / no progress
+            last_sum = sum;
+            int unfinished = 0;
+            for (int g = 0; g < G; ++g)
+                if (e->active[g] && h_target[g] > h_done[g]) ++unfinished;
+            plan_sit(unfinished);
+            const int extra = std::max<int64_t>(mx, (sum + cap_rows - 1) / cap_rows);
+            for (int k = 0; k < extra && rc == 0; ++k) rc = one_sim();
+            if (rc) return rc;
+        }
+    }
+    if (harvest_rows(launch)) return 1;
+    if (oversub && sims_wanted > 0)
+        e->ask_frac = static_cast<double>(e->rs_rows_live - rows_live_before) / static_cast<double>(sims_wanted);
     if (launch_timing) {
         const auto lt1 = std::chrono::steady_clock::now();
         (void)hipStreamSynchronize(e->stream);
@@ -787,6 +932,41 @@ int ao_search(ao_engine* e, ao_net* net, const uint8_t* active, const int8_t* ta
               double* visit, double* policy) {
     return search_impl(e, net, active, tau, pi, visit, policy, true);
 }
+
+int ao_set_row_cap(ao_engine* e, int32_t rows) {
+    if (rows < 0) return e->fail("ao_set_row_cap: negative");
+    if (e->in_move) return e->fail("ao_set_row_cap inside a move");
+    e->row_cap = rows;
+    return 0;
+}
+
+int ao_row_stats(ao_engine* e, int64_t* launches, int64_t* rows_live, int64_t* rows_launched, int64_t* waits) {
+    if (launches) *launches = e->rs_launches;
+    if (rows_live) *rows_live = e->rs_rows_live;
+    if (rows_launched) *rows_launched = e->rs_rows_launched;
+    if (waits) *waits = e->rs_waits;
+    return 0;
+}
+
+int ao_set_eval_log(ao_engine* e, const int32_t* games, int32_t n, float* dev_log, int64_t capacity_floats) {
+    if (n < 0 || n > e->G) return e->fail("ao_set_eval_log: bad game count");
+    if (e->in_move) return e->fail("ao_set_eval_log inside a move");
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    for (int k = 0; k < n; ++k)
+        if (games[k] < 0 || games[k] >= e->G) return e->fail("ao_set_eval_log: game index out of range");
+    if (n > 0) {
+        if (!dev_log) return e->fail("ao_set_eval_log: null log buffer");
+        AO_HIP(e, hipMemcpyAsync(e->d_log_games, games, sizeof(int32_t) * n, hipMemcpyHostToDevice, e->stream));
+        AO_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    e->log_n = n;
+    e->log_dev = dev_log;
+    e->log_cap = n > 0 ? capacity_floats : 0;
+    e->log_sim = 0;
+    return 0;
+}
+
+int ao_eval_log_count(ao_engine* e) { return static_cast<int>(e->log_sim); }
 
 int ao_fp16_range_events(ao_engine* e, int64_t* moves_repeated, int64_t* games_redone) {
     if (moves_repeated) *moves_repeated = e->fp16_events;

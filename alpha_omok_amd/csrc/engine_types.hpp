@@ -31,7 +31,11 @@ constexpr int32_t CH_UNVISITED = -1;  // reference: child record exists with n =
 constexpr int32_t CH_TERMINAL = -2;   // visited child whose position ends the game
 
 // leaf status written by the select kernel for the expand/backup kernel
-enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3 };
+// LS_WAIT / LS_WAIT_ROOT (round 5, rows handed out per simulation): the descent of this simulation is done -- path and leaf
+// position are stored -- but every row of the evaluation batch was taken (TreeParams::row_cap); the game asks again in the
+// next launch, before anyone else, and is expanded one launch later. Nothing observable changes: a game's search is strictly
+// sequential either way.
+enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3, LS_WAIT = 4, LS_WAIT_ROOT = 5 };
 
 // per-game error bits
 enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
@@ -86,8 +90,16 @@ struct TreeParams {
     float* batch_nchw;    // [G][C][B][B] or null
     uint8_t* batch_u8;    // bit planes [G][u8_row] (byte per cell, bit q = plane q) or null: the split-fp16 network's input
     int u8_row;           // 128 (A <= 128) or 256
-    const int32_t* row_of_game;  // row of game g in the native network's batch (active games are packed to the front:
-                          // the network runs on the active games only), or null = g. Not used for batch_nchw / external p, v
+    int32_t* row_of_game; // row of game g in the native network's batch, or null = g (batch_nchw / external p, v). Two regimes:
+                          // `live` null -- the host packed the ACTIVE games to the front once per move (the fused per-board step, the
+                          // step-wise API); `live` set -- the selection hands out rows PER SIMULATION and writes this array:
+    unsigned* live;       // rows taken so far by THIS launch's selections (zero before the launch), or null. A game whose new leaf
+                          // needs the network takes the next row with one returning atomic; terminal leaves take none (the
+                          // reference evaluates them and throws the result away, agents.py:171-178,216-221 -- SURVEY Q9), so the
+                          // trunk sees live rows only: 11 - 19 % fewer with a trained network. The trunk kernels read the same word.
+    unsigned sit_n, sit_off;  // over-subscription: the games g with (g + sit_off) mod G < sit_n start no descent in this launch
+    unsigned row_cap;     // rows one simulation may hand out (the evaluation batch the trunk is launched for); a game that finds
+                          // them taken waits for the next launch (LS_WAIT): more games than rows = over-subscription
     const float* policy;  // [G][A]
     const float* value;   // [G]
     // move results

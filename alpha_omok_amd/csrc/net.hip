@@ -352,7 +352,10 @@ int net_step_params(ao_net* n, int boards, float* policy, float* value, StepNet*
 
 // parts (per-board path only): 1 = conv1, 2 = the residual blocks, 4 = the heads -- the fused per-game step (k_step_board)
 // computes conv1 and the heads itself and asks for the blocks alone.
-int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s, int in_kind, int parts) {
+// live / row_cap: rows handed out per simulation (engine_types.hpp TreeParams::live) -- `boards` is then the CAPACITY the kernels are
+// launched for and the split-fp16 kernels skip the 16-board groups beyond the live count; null = all `boards` rows are live.
+int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, float* value, hipStream_t s, int in_kind, int parts,
+                   const unsigned* live, unsigned row_cap) {
     if (!n->finalized) return n->fail("ao_net_finalize has not been called");
     NET_HIP(n, hipSetDevice(n->device));
     if (ensure_workspace(n, boards)) return 1;
@@ -505,6 +508,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.ovf = n->d_status;
             a.res = !(l & 1) ? 1 : 0;
             a.nch = groups;
+            a.live = live; a.row_cap = row_cap;
             const dim3 grid(rowk ? (groups + 7) / 8 * 8 * 4 * n->B : (groups + 7) / 8 * 8 * ks), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
             if (rowk) {
@@ -559,6 +563,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layer.ovf = n->d_status;
             a.res = (l > 0 && !(l & 1)) ? 1 : 0;
             a.nch = nchh;
+            a.live = live; a.row_cap = row_cap;
             const dim3 grid(groups * nchh * nxt), block(512);
             const bool timed = n->timing && l > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
@@ -612,6 +617,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         a.wp_t = n->wp_t; a.bp = n->bp; a.w1_t = n->w1_t; a.b1 = n->b1; a.w2 = n->w2; a.b2 = n->b2;
         a.policy = policy;
         a.value = value;
+        a.live = live; a.row_cap = row_cap;
         for (int l = 0; l < a.nlayers; ++l) {
             a.layers[l].wh = n->convh_wh[l];
             a.layers[l].wl = n->convh_wl[l];
@@ -1073,7 +1079,7 @@ int ao_net_forward(ao_net* n, const float* dev_planes_nchw, int batch, float* de
     const size_t total = static_cast<size_t>(boards) * n->A;
     hipLaunchKernelGGL(ao::k_nchw_to_il, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s,
                        dev_planes_nchw, reinterpret_cast<float4*>(n->il_in), batch, n->C, n->A, nchq, boards, group);
-    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s, 1, 7)) return 1;
+    if (ao::net_forward_il(n, n->il_in, batch, pol, val, s, 1, 7, nullptr, 0u)) return 1;
     if (boards != batch) {
         NET_HIP(n, hipMemcpyAsync(dev_policy, n->tmp_p, sizeof(float) * batch * n->A, hipMemcpyDeviceToDevice, s));
         NET_HIP(n, hipMemcpyAsync(dev_value, n->tmp_v, sizeof(float) * batch, hipMemcpyDeviceToDevice, s));

@@ -43,6 +43,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// Rows handed out per simulation (engine_types.hpp, TreeParams::live): the tree kernel counts the live rows of this
+// simulation's evaluation batch in one device word, the network kernels are launched for the batch's CAPACITY and read the word:
+// a 16-board group without a live row has nothing to do (no host read-back in the loop). Null = every group is live.
+__device__ __forceinline__ int live_groups16(const unsigned* live, unsigned row_cap, int groups) {
+    if (!live) return groups;
+    unsigned n = *live;   // (written by the previous kernel of the stream: a scalar load)
+    n = n < row_cap ? n : row_cap;
+    const int lg = static_cast<int>((n + 15u) >> 4);
+    return lg < groups ? lg : groups;
+}
+
 template <int NX>
 struct StepRegs {
     Frag x[NX];

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
 
     // XCD-aware placement: the KS workgroups of a group share its input rows -- same XCD, same L2 (blocks are dealt
     // round robin over the 8 XCDs)
-    const int groups = a.nch;
+    const int groups = live_groups16(a.live, a.row_cap, a.nch);   // (groups without a live row: nothing to do)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, rr = bid >> 3;
     const int j = rr % KS, grp = (rr / KS) * 8 + xcd;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
     constexpr int A = BW * BW;
     constexpr int NFR = BW * NCI * 2;
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];   // [NFR][64]
-    const int groups = a.nch;
+    const int groups = live_groups16(a.live, a.row_cap, a.nch);   // (groups without a live row: nothing to do)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, rr = bid >> 3;
     const int j = rr % KS, y = (rr / KS) % BW, grp = (rr / (KS * BW)) * 8 + xcd;

@@ -23,6 +23,8 @@ struct TrunkHArgs {
     const float *w3, *sc3, *sh3, *wp_t, *bp, *w1_t, *b1, *w2, *b2;
     float* policy;
     float* value;
+    const unsigned* live;   // live rows of this simulation's batch (net_common.hpp, live_groups16) or null
+    unsigned row_cap;
     TrunkHLayer layers[kMaxTrunkLayers];
 };
 
@@ -742,6 +744,8 @@ struct LayerHArgs {
     uint4* dst;
     TrunkHLayer layer;
     int res, nch;
+    const unsigned* live;   // live rows of this simulation's batch (net_common.hpp, live_groups16) or null
+    unsigned row_cap;
 };
 
 template <int BW, int XT, int NC32, int KIND>
@@ -752,6 +756,7 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
     const int xt = blockIdx.x % NXT;
     const int rest = blockIdx.x / NXT;
     const int grp = rest / a.nch, ch = rest - grp * a.nch;
+    if (grp >= live_groups16(a.live, a.row_cap, grp + 1)) return;   // no live row in this group (rows handed out per simulation)
     const int base = BW / a.nch, extra = BW % a.nch;
     const int yb = ch * base + (ch < extra ? ch : extra);
     const int ye = yb + base + (ch < extra ? 1 : 0);
@@ -776,6 +781,7 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     constexpr int A = BW * BW;
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];  // [2][row fragments][64] uint4
     const int grp = blockIdx.x;
+    if (grp >= live_groups16(a.live, a.row_cap, grp + 1)) return;   // no live row in this group (rows handed out per simulation)
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // this wave's output tile
     // first activation byte of this group, in uint4 units (AO_KO 5 / 6: groups share buffers, timing experiment only)

@@ -444,13 +444,57 @@ __device__ __forceinline__ void encode_planes(const TreeParams& p, int g, const 
 struct GameHdr {
     int valid = 0;
     int is_active, done, target, arena, root_node, batch_row, mtpos;
+    int prev_status;   // leaf status the expansion found: LS_WAIT / LS_WAIT_ROOT = the leaf of an earlier launch still needs its row
 };
 
-template <int NCH>
+// Rows of the evaluation batch handed out per simulation (TreeParams::live). take(need) is called exactly ONCE by every wave of
+// the kernel, at one place of select_game, and returns this wave's row, or -1 (none needed / the batch of this simulation is
+// full). Returning atomics on ONE word serialise at ~11 ns each on the MI355X (tools/row_alloc_atomics.hip,
+// profiles/r5a_row_alloc_atomics.txt: 3620 of them stretch a 3 us kernel to 44 us), so the waves of a workgroup meet at a barrier
+// and ONE of them adds the workgroup's count (TakeRowWG: 15 us for 905 workgroups; 1.3 us on top of a 50 us kernel whose waves
+// arrive spread out). TakeRowWave: one game per workgroup (k_select: once per move).
+struct TakeRowWave {
+    unsigned* live; unsigned cap;
+    __device__ __forceinline__ int operator()(bool need) const {
+        unsigned r = 0xffffffffu;
+        if (need && lane_id() == 0) r = atomicAdd(live, 1u);
+        r = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(r)));
+        return r < cap ? static_cast<int>(r) : -1;
+    }
+};
+template <int WAVES>
+struct TakeRowWG {
+    unsigned* live; unsigned cap;
+    unsigned* s_need;   // [WAVES + 1] LDS: each wave's request, then the workgroup's first row
+    __device__ __forceinline__ int operator()(bool need) const {
+        const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+        if (lane_id() == 0) s_need[w] = need ? 1u : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tot = 0;
+#pragma unroll
+            for (int i = 0; i < WAVES; ++i) tot += s_need[i];
+            s_need[WAVES] = tot ? atomicAdd(live, tot) : 0u;
+        }
+        __syncthreads();
+        unsigned r = s_need[WAVES];
+#pragma unroll
+        for (int i = 0; i < WAVES; ++i) r += (i < w) ? s_need[i] : 0u;
+        r = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(r)));
+        return (need && r < cap) ? static_cast<int>(r) : -1;
+    }
+};
+struct TakeRowNone {   // rows are not handed out by the kernel (TreeParams::live == nullptr)
+    __device__ __forceinline__ int operator()(bool) const { return -1; }
+};
+
+// `exists` false: a wave of the workgroup beyond the last game -- it only keeps the row hand-out's barrier company.
+template <int NCH, class TakeRow = TakeRowNone>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr,
-                                            const GameHdr* hdr = nullptr) {
+                                            const GameHdr* hdr = nullptr, const TakeRow& take = TakeRow(), const bool exists = true) {
     const int lane = lane_id();
     AO_TT(3);
+    if (!exists) { if (p.live) (void)take(false); return; }
     // The descent is a chain of dependent memory round trips (one wave per game has nothing else to
     // overlap them with), so every step requests all it can in ONE trip: first the game header ...
     const bool have = hdr != nullptr && hdr->valid;
@@ -458,9 +502,40 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     const int done = have ? hdr->done : p.sims_done[g], target = have ? hdr->target : p.sims_target[g];
     const int arena = have ? hdr->arena : p.cur[g];
     int node = have ? hdr->root_node : p.root_node[g];
-    const int batch_row = have ? hdr->batch_row : (p.row_of_game ? p.row_of_game[g] : g);
-    if (!is_active || done >= target) {
+    int batch_row = have ? hdr->batch_row : (p.row_of_game ? p.row_of_game[g] : g);
+    const int prev = !p.live ? LS_IDLE : have ? hdr->prev_status : p.leaf_status[g];
+    // what this launch does for the game: 0 nothing, 1 its waiting leaf gets a row, 2 a descent
+    int mode = 2;
+    if (!is_active || done >= target) mode = 0;
+    else if (prev == LS_WAIT || prev == LS_WAIT_ROOT) mode = 1;
+    else if (p.sit_n > 0) {
+        // over-subscribed (more games than rows per simulation): this launch's share of the games sits out -- a window of
+        // game indices that moves on by its own length with every launch, so every game sits out equally often and all of them
+        // reach their simulation count within a launch or two of each other. (Who finds the batch full is NOT left to the order
+        // of arrival: the deepest descents arrive last, every time.)
+        unsigned k = static_cast<unsigned>(g) + p.sit_off;
+        k = k >= static_cast<unsigned>(p.G) ? k - static_cast<unsigned>(p.G) : k;
+        if (k < p.sit_n) mode = 3;
+    }
+    if (mode == 0 || mode == 3) {
         if (lane == 0) p.leaf_status[g] = LS_IDLE;
+        if (p.live) (void)take(false);
+        return;
+    }
+    if (mode == 1) {
+        // A leaf that found the batch full in an earlier launch: no second descent, no draw from the stream. It takes its row
+        // with a wave's own atomic, at once -- before the games that expand and descend first get anywhere near theirs.
+        const int r = TakeRowWave{p.live, p.row_cap}(true);
+        if (r >= 0) {
+            const PosR wl = pos_load(p.leaf_pos + g);
+            encode_planes<NCH>(p, g, wl, r, lds_bits);
+            if (lane == 0) {
+                p.row_of_game[g] = r;
+                p.leaf_status[g] = prev == LS_WAIT ? LS_EXPAND : LS_EXPAND_ROOT;
+                atomicAdd(p.stats + static_cast<size_t>(g) * 4 + 3, 1u);
+            }
+        }
+        (void)take(false);   // (mode 1 exists with p.live only)
         return;
     }
     MtDev mt;
@@ -469,6 +544,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
 
     int depth = 0;
     int status = LS_EXPAND_ROOT;
+    bool failed = false;
     unsigned levels = 0, ties = 0;
     int path_n[NCH], path_e[NCH];
 #pragma unroll
@@ -566,12 +642,12 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                     else r -= cnt;
                 }
             }
-            if (esel < 0 || depth >= p.maxd) {  // NaN priors (policy summed to 0) or an inconsistent tree
-                if (lane == 0) { atomicOr(&p.err[g], ERR_PATH); p.leaf_status[g] = LS_IDLE; }
-                mt.close();
-                return;
+            if (esel < 0 || depth >= p.maxd || depth >= 64 * NCH) {  // NaN priors (policy summed to 0) or an inconsistent tree (the path registers hold 64 * NCH entries)
+                failed = true;
+                break;
             }
-            // the path stays in registers (entry d in lane d & 63 of chunk d >> 6; maxd = A + 2 <= 64 * NCH) and is written once
+            // the path stays in registers (entry d in lane d & 63 of chunk d >> 6; a consistent tree is at most A <= 64 * NCH levels deep,
+            // anything deeper was refused above) and is written once
             // after the descent: two stores per level kept the next level's loads behind their acknowledgement
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -602,6 +678,17 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         }
     }
     AO_TT(8);
+    const bool to_expand = !failed && (status == LS_EXPAND || status == LS_EXPAND_ROOT);
+    bool wait = false;
+    if (p.live) {   // the leaf's row in this simulation's batch (every wave of the workgroup gets here or to one of the take(false) above)
+        batch_row = take(to_expand);
+        wait = to_expand && batch_row < 0;
+    }
+    if (failed) {
+        if (lane == 0) { atomicOr(&p.err[g], ERR_PATH); p.leaf_status[g] = LS_IDLE; }
+        mt.close();
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int d = lane + 64 * c;
@@ -610,22 +697,23 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             p.path_edge[static_cast<size_t>(g) * p.maxd + d] = static_cast<int16_t>(path_e[c]);
         }
     }
-    if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
+    if (to_expand) {
         lp.nchild = 0;
         if (lane == 0) pos_store(p.leaf_pos + g, lp);
         AO_TT(9);
-        encode_planes<NCH>(p, g, lp, batch_row, lds_bits);
+        if (!wait) encode_planes<NCH>(p, g, lp, batch_row, lds_bits);
     }
     AO_TT(10);
     if (lane == 0) {
-        p.leaf_status[g] = status;
+        p.leaf_status[g] = wait ? (status == LS_EXPAND ? LS_WAIT : LS_WAIT_ROOT) : status;
         p.path_len[g] = depth;
+        if (p.live && to_expand && !wait) p.row_of_game[g] = batch_row;
         // per-game counters (a shared word would serialise 4 x G atomics per simulation); no-return atomics: as plain
         // read-modify-writes they were one more dependent round trip before the kernel could end
         unsigned* st = p.stats + static_cast<size_t>(g) * 4;
         atomicAdd(st + 0, levels);
         atomicAdd(st + 1, ties);
-        atomicAdd(st + ((status == LS_TERMINAL) ? 2 : 3), 1u);
+        if (!wait) atomicAdd(st + ((status == LS_TERMINAL) ? 2 : 3), 1u);
     }
     AO_TT(11);
     mt.close();
@@ -799,9 +887,10 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         hdr->arena = arena;
         hdr->batch_row = row;
         hdr->done = done;
+        hdr->prev_status = status;
         hdr->valid = 1;
     }
-    if (status == LS_IDLE) return;
+    if (status == LS_IDLE || status == LS_WAIT || status == LS_WAIT_ROOT) return;   // (a waiting leaf: see select_game)
     float v = 0.f;
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         if (newn >= p.cap) {

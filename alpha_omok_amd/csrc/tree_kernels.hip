@@ -26,7 +26,7 @@ namespace ao {
 template <int NCH>
 __global__ __launch_bounds__(64) void k_select(TreeParams p) {
     __shared__ uint32_t s_mt[624];
-    select_game<NCH>(p, blockIdx.x, s_mt);
+    select_game<NCH>(p, blockIdx.x, s_mt, nullptr, nullptr, TakeRowWave{p.live, p.row_cap});
 }
 
 template <int NCH>
@@ -50,15 +50,18 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     __shared__ uint8_t s_ord[kGamesPerWG][256];
     __shared__ double s_prior[kGamesPerWG][256];
     __shared__ int16_t s_tab[kGamesPerWG][256];
+    __shared__ unsigned s_need[kGamesPerWG + 1];
     const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     const int g = blockIdx.x * kGamesPerWG + w;
-    if (g >= p.G) return;
+    const bool exists = g < p.G;
+    if (!exists && !p.live) return;
     AO_TT(0);
     GameHdr hdr;
-    expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w], &hdr);
+    if (exists) expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w], &hdr);
     wsync();
     AO_TT(1);
-    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr);
+    // (rows handed out per simulation: the waves of the workgroup meet once inside select_game, see TakeRowWG)
+    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr, TakeRowWG<kGamesPerWG>{p.live, p.row_cap, s_need}, exists);
     AO_TT(2);
 }
 
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(64) void k_begin_move(TreeParams p) {
     const int g = blockIdx.x;
     const int lane = lane_id();
     if (p.active && !p.active[g]) return;
-    if (lane == 0) p.sims_done[g] = 0;
+    if (lane == 0) { p.sims_done[g] = 0; p.leaf_status[g] = LS_IDLE; }   // (no leaf of an aborted move is left waiting for a row)
     const int node = p.root_node[g];
     if (!(p.gflags[g] & 1) || node < 0) return;
     const size_t slot = node_slot(p, p.cur[g], g, node);
@@ -366,6 +369,24 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games,
     }
 }
 
+// k_eval_log (ao_set_eval_log, a test / debugging hook): the policy row and the value the listed games' leaves were evaluated
+// with in this simulation, copied out of the evaluation batch -- what lets the parity tests replay ao_search through the oracle
+__global__ void k_eval_log(const int32_t* games, const int32_t* row_of_game, const float* policy, const float* value, int A, float* out,
+                           const int32_t* sims_done, const int32_t* leaf_status, int what) {
+    const int k = blockIdx.x;
+    const int g = games[k];
+    const int row = row_of_game[g];
+    float* o = out + static_cast<size_t>(k) * (A + 3);
+    if (what & 1) {
+        for (int i = threadIdx.x; i < A; i += blockDim.x) o[i] = policy[static_cast<size_t>(row) * A + i];
+        if (threadIdx.x == 0) o[A] = value[row];
+    }
+    if ((what & 2) && threadIdx.x == 0) {
+        o[A + 1] = static_cast<float>(sims_done[g]);      // simulations the game has completed: this record belongs to the next one ...
+        o[A + 2] = static_cast<float>(leaf_status[g]);    // ... if its leaf is waiting for this evaluation (LS_EXPAND / _ROOT) or is terminal
+    }
+}
+
 // k_reset: ZeroAgent.reset() for the masked games
 __global__ void k_reset(TreeParams p, const uint8_t* mask) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +455,10 @@ void launch_walk(const TreeParams& p, int count, const int32_t* games, const int
     const size_t lds = static_cast<size_t>(p.cap) * 4 + 16;
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_walk<NCH>, dim3(count), dim3(64), lds, s, p, games, extra, stride, m,
                                                    prev_known, status_out));
+}
+void launch_eval_log(const int32_t* games, int n, const int32_t* row_of_game, const float* policy, const float* value, int A,
+                     float* out, const int32_t* sims_done, const int32_t* leaf_status, int what, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_log, dim3(n), dim3(128), 0, s, games, row_of_game, policy, value, A, out, sims_done, leaf_status, what);
 }
 void launch_reset(const TreeParams& p, const uint8_t* mask, hipStream_t s) {
     hipLaunchKernelGGL(k_reset, dim3((p.G + 255) / 256), dim3(256), 0, s, p, mask);

@@ -320,6 +320,27 @@ class Engine:
         self._check(self._L.ao_search_stats(self._h, *[C.byref(x) for x in v]), "ao_search_stats")
         return dict(levels=v[0].value, ties=v[1].value, terminal=v[2].value, evaluated=v[3].value)
 
+    def set_row_cap(self, rows):
+        """rows > 0: `search` hands out the evaluation-batch rows per simulation (terminal leaves take none) and evaluates at
+        most `rows` leaves per simulation -- fewer rows than games = over-subscription; 0: the per-move packing (ao_set_row_cap)."""
+        self._check(self._L.ao_set_row_cap(self._h, int(rows)), "ao_set_row_cap")
+        self.row_cap = int(rows)
+
+    def row_stats(self):
+        """dict(launches, rows_live, rows_launched, waits) over the searches that handed out rows per simulation (ao_row_stats)."""
+        v = [C.c_int64(0) for _ in range(4)]
+        self._check(self._L.ao_row_stats(self._h, *[C.byref(x) for x in v]), "ao_row_stats")
+        return dict(launches=v[0].value, rows_live=v[1].value, rows_launched=v[2].value, waits=v[3].value)
+
+    def set_eval_log(self, games, dev_ptr=None, capacity_floats=0):
+        """Test hook (ao_set_eval_log): record the (policy, value) the listed games' leaves are evaluated with in `search`."""
+        g = np.ascontiguousarray(list(games), np.int32)
+        self._check(self._L.ao_set_eval_log(self._h, _ptr(g, C.c_int32) if g.size else None, int(g.size), dev_ptr,
+                                            int(capacity_floats)), "ao_set_eval_log")
+
+    def eval_log_count(self):
+        return int(self._L.ao_eval_log_count(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.ao_destroy(self._h)

@@ -159,6 +159,30 @@ int ao_fp16_range_events(ao_engine *e, int64_t *moves_repeated, int64_t *games_r
 int ao_search_stats(ao_engine *e, int64_t *levels, int64_t *ties, int64_t *terminal,
                     int64_t *evaluated);
 
+/* Rows of the evaluation batch per simulation in ao_search (new; the reference evaluates one leaf at a time and runs the net on
+ * terminal leaves only to throw the result away, agents.py:171-178,216-221 -- SURVEY Q9).
+ *   rows == 0 (default): the host packs the active games to the front of the batch once per move; a game whose leaf is terminal
+ *     keeps its (stale) row in that simulation's batch.
+ *   rows > 0: the tree kernel hands out the rows PER SIMULATION -- terminal leaves take none -- and counts the live rows in a
+ *     device word the trunk kernels read (groups without a live row exit at once). `rows` bounds the batch of one simulation; with
+ *     MORE active games than rows (over-subscription, e.g. 5120 games on the 4096 rows the resident trunk fills the chip with)
+ *     a share of the games sits out every launch in turn and a leaf that still finds the batch full is evaluated one launch
+ *     later; ao_search runs until every game has its simulations. Every game's search stays strictly sequential: visits,
+ *     priors, actions and RNG streams are bit-identical to rows == 0 for a network whose result does not depend on a board's
+ *     neighbours in the batch. */
+int ao_set_row_cap(ao_engine *e, int32_t rows);
+/* since ao_create, over the ao_search calls that handed out rows per simulation: network launches, live rows they evaluated,
+ * rows they were launched for (launches x batch capacity), leaves that found their simulation's batch full */
+int ao_row_stats(ao_engine *e, int64_t *launches, int64_t *rows_live, int64_t *rows_launched, int64_t *waits);
+/* Test / debugging hook: what the network returned to the listed games during ao_search. Network launch s (counted from 0
+ * when this function was called, over all ao_search calls since) writes, for listed game k, a record of A + 3 floats to dev_log[(s * n + k) * (A + 3) ...]: the policy row
+ * and the value at the game's row of the evaluation batch, the number of simulations the game has completed, and its leaf
+ * status (1 / 2: the leaf waits for exactly this evaluation; 3: terminal leaf, no evaluation -- the reference evaluates and
+ * discards; 0 / 4 / 5: nothing of this game was evaluated in this launch). Launches beyond capacity_floats are not recorded;
+ * n == 0 switches the log off. ao_eval_log_count: the launches recorded so far. */
+int ao_set_eval_log(ao_engine *e, const int32_t *host_games, int32_t n, float *dev_log, int64_t capacity_floats);
+int ao_eval_log_count(ao_engine *e);
+
 /* ---- policy/value network ---- replaces model.PVNet(...).forward in eval() mode
  * (model.py:76-104). Parameters are given under their state_dict names.
  * planes: a multiple of 32 in 32 .. 256 (model.py:76-85 takes any width). 128 planes (the reference's OUT_PLANES,

@@ -73,3 +73,46 @@ def test_bench_gpus_n_refuses_without_n_devices():
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert r.stdout.strip() == "", "a bench line was printed although the requested GPUs are not there"
     assert "--gpus 2" in r.stderr and "visible" in r.stderr
+
+
+def test_build_lists_cover_every_source_and_header_under_csrc():
+    """build.HEADERS / build.SOURCES are what `_stale` watches and what `source_hash()` (-> bench `csrc_sha16`, the key that
+    lets a profiles/r*_traffic.json speak for a bench run) covers. Round 4 shipped net_layer_ksplit.hpp outside HEADERS: an
+    edit of that header alone would not have rebuilt net.o, and the hash was blind to two kernels. Every file a translation
+    unit (transitively) includes by name, and every .hip / .hpp on disk, must be in the lists."""
+    import re
+    from alpha_omok_amd import build as b
+    on_disk_hip = sorted(f for f in os.listdir(b.CSRC) if f.endswith(".hip"))
+    on_disk_hpp = sorted(f for f in os.listdir(b.CSRC) if f.endswith(".hpp"))
+    assert sorted(b.SOURCES) == on_disk_hip
+    local_headers = sorted(h for h in b.HEADERS if not os.path.isabs(h))
+    assert local_headers == on_disk_hpp
+    assert any(os.path.isabs(h) and h.endswith(os.path.join("include", "omok_hip.h")) for h in b.HEADERS)
+    inc = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    for f in on_disk_hip + on_disk_hpp:
+        with open(os.path.join(b.CSRC, f)) as fh:
+            for name in inc.findall(fh.read()):
+                path = os.path.normpath(os.path.join(b.CSRC, name))
+                assert os.path.exists(path), "%s includes %s which does not exist" % (f, name)
+                listed = [os.path.normpath(h if os.path.isabs(h) else os.path.join(b.CSRC, h)) for h in b.HEADERS]
+                assert path in listed, "%s includes %s, which build.HEADERS does not list" % (f, name)
+    # the hash follows a header's CODE (not its comments)
+    h0 = b.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h0)
+    target = os.path.join(b.CSRC, "net_layer_ksplit.hpp")
+    with open(target) as fh:
+        text = fh.read()
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        import io
+        if os.path.abspath(path) == target:
+            return io.StringIO(text + "\nstatic int ao_hash_probe_;\n")
+        return real_open(path, *a, **k)
+    import builtins
+    builtins.open = fake_open
+    try:
+        h1 = b.source_hash()
+    finally:
+        builtins.open = real_open
+    assert h1 != h0, "source_hash() does not cover net_layer_ksplit.hpp"
