@@ -69,6 +69,7 @@ struct ao_engine {
     static constexpr int kLive = 2048;
     unsigned* d_live = nullptr;
     unsigned* h_live = nullptr;                           // pinned [kLive]
+    unsigned* d_ctl = nullptr;                            // [2][4] the sit-out window of the current / the next launch (tree_device.hpp, sit_window)
     int row_cap = 0;
     double ask_frac = 1.0;                                // rows asked for per simulation of a game in the last over-subscribed move (1 - terminal share)
     int64_t rs_launches = 0, rs_rows_live = 0, rs_rows_launched = 0, rs_waits = 0;   // ao_row_stats
@@ -244,9 +245,27 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.il_group = ao::kGroup;
     p.c_puct = c.c_puct;
 
-    const size_t slots = static_cast<size_t>(2) * G * p.cap;
     p.rec = ao::node_rec_bytes(Ap);                        // one interleaved record per node (engine_types.hpp)
-    if (dev_alloc(e, &p.arena, slots * p.rec)) return 1;
+    // The default arena (ao_config.node_cap == 0) is sized from the device's TOTAL memory: other tenants -- a second engine, torch's
+    // training state, a device replay -- may leave less. It then shrinks (x 3/4 per attempt, never below 4 x (sims + 1)) until the
+    // allocation succeeds; ao_node_cap reports what was chosen. An explicit node_cap fails as it always did.
+    for (;;) {
+        const size_t slots = static_cast<size_t>(2) * G * p.cap;
+        void* arena = nullptr;
+        const hipError_t st = hipMalloc(&arena, std::max<size_t>(slots * p.rec, 16));
+        if (st == hipSuccess) {
+            e->allocs.push_back(arena);
+            p.arena = static_cast<unsigned char*>(arena);
+            break;
+        }
+        (void)hipGetLastError();
+        const int floor_cap = 4 * (c.sims + 1);
+        if (cfg->node_cap != 0 || p.cap <= floor_cap)
+            return e->fail(std::string("hipMalloc(") + std::to_string(slots * p.rec) + " B for the tree arenas): " + hipGetErrorString(st));
+        p.cap = std::max(floor_cap, p.cap / 4 * 3);
+        c.node_cap = p.cap;
+        p.keep_max = c.node_cap - c.sims - 1;
+    }
     if (dev_alloc(e, &p.cur, G) || dev_alloc(e, &p.root_node, G) || dev_alloc(e, &p.nodes_used, G) ||
         dev_alloc(e, &p.rootpos, G) || dev_alloc(e, &p.mt, static_cast<size_t>(G) * 624) ||
         dev_alloc(e, &p.mtpos, G) || dev_alloc(e, &p.noise_buf, static_cast<size_t>(G) * Ap) ||
@@ -268,12 +287,13 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.u8_row = A <= 128 ? 128 : 256;
     if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, 2 * static_cast<size_t>(G))) return 1;
     if (dev_alloc(e, &e->d_mt_backup, static_cast<size_t>(G) * 624) || dev_alloc(e, &e->d_pos_backup, G)) return 1;
-    if (dev_alloc(e, &e->d_live, ao_engine::kLive) || dev_alloc(e, &e->d_log_games, G)) return 1;
+    if (dev_alloc(e, &e->d_live, ao_engine::kLive) || dev_alloc(e, &e->d_log_games, G) || dev_alloc(e, &e->d_ctl, 8)) return 1;
     AO_HIP(e, hipMemsetAsync(e->d_row, 0, sizeof(int32_t) * 2 * G, e->stream));
     AO_HIP(e, hipMemsetAsync(e->d_live, 0, sizeof(unsigned) * ao_engine::kLive, e->stream));
     p.row_of_game = nullptr;
     p.live = nullptr;
     p.row_cap = 0;
+    p.ctl = nullptr; p.ctl_cur = 0; p.live_prev = nullptr; p.row_target = 0;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
     p.batch_u8 = nullptr;
     e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
@@ -296,7 +316,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_noise), sizeof(double) * G * Ap, hipHostMallocDefault));
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_out), sizeof(double) * 3 * G * A, hipHostMallocDefault));
     AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_i32), sizeof(int32_t) * 4 * G, hipHostMallocDefault));
-    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_live), sizeof(unsigned) * ao_engine::kLive, hipHostMallocDefault));
+    AO_HIP(e, hipHostMalloc(reinterpret_cast<void**>(&e->h_live), sizeof(unsigned) * (ao_engine::kLive + 8), hipHostMallocDefault));
     std::memset(e->h_noise, 0, sizeof(double) * G * Ap);
 
     e->moves.assign(G, {});
@@ -730,6 +750,7 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         AO_HIP(e, hipMemcpyAsync(e->d_row, e->h_row.data(), sizeof(int32_t) * 2 * e->G, hipMemcpyHostToDevice, e->stream));
     }
     int launch = 0, harvested = 0;   // selection launches of this move so far (launch i counts its rows in slot i % kLive); slots already summed up
+    auto slot = [&](int i) -> unsigned* { return dynamic ? e->d_live + (i % ao_engine::kLive) : nullptr; };
     // Over-subscription (more active games than rows per simulation). Every launch a window of the game indices sits out, sized so
     // that the games that do descend ask for about cap_rows rows -- a share `ask_frac` of them does (the rest ends at terminal
     // leaves), measured over the previous move of this engine, less three standard deviations of that binomial; the window moves on
@@ -739,27 +760,46 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     int64_t sims_wanted = 0;
     for (int g = 0; g < e->G; ++g)
         if (e->active[g]) sims_wanted += (e->status[g] == AO_ROOT_FRESH) ? e->S + 1 : e->S;
-    unsigned sit_idx = 0;
-    auto plan_sit = [&](int unfinished) {
-        sit_idx = 0;
-        if (!oversub || unfinished <= 0) return;
+    unsigned sit_idx = 0;       // the window the move starts with (the host's estimate); the device takes it from there (sit_window)
+    unsigned row_target = static_cast<unsigned>(cap_rows);
+    if (oversub) {
         const double f = std::min(1.0, std::max(0.5, e->ask_frac));
-        const double slack = 3.0 * std::sqrt(static_cast<double>(cap_rows) * (1.0 - f));
-        const double askers = std::min<double>(unfinished, std::floor((cap_rows - slack) / f));
-        sit_idx = static_cast<unsigned>(std::lround((unfinished - askers) * e->G / static_cast<double>(unfinished)));
+        const double slack = 2.5 * std::sqrt(static_cast<double>(cap_rows) * (1.0 - f)) + 4.0;
+        row_target = static_cast<unsigned>(std::max(1.0, cap_rows - slack));
+        const double askers = std::min<double>(rows, std::floor(row_target / f));
+        sit_idx = static_cast<unsigned>(std::lround((rows - askers) * e->G / static_cast<double>(rows)));
         if (sit_idx >= static_cast<unsigned>(e->G)) sit_idx = static_cast<unsigned>(e->G) - 1u;
-    };
+        // the move STARTS with the window that is safe for any demand -- as many games descend as there are rows -- and the
+        // controller opens it within a handful of launches: the first descents of a move ask for more rows than its average
+        // (measured: 4741 - 4957 asked of 4096 at the average's window, ~2000 leaves per move sent waiting), and a leaf that
+        // waits costs its game a launch at the END of the move, when the batch is nearly empty
+        const double askers0 = std::min<double>(rows, row_target);
+        unsigned sit0 = static_cast<unsigned>(std::lround((rows - askers0) * e->G / static_cast<double>(rows)));
+        if (sit0 >= static_cast<unsigned>(e->G)) sit0 = static_cast<unsigned>(e->G) - 1u;
+        const float sf = static_cast<float>(sit0);
+        unsigned* init = e->h_live + ao_engine::kLive;   // (pinned; every move ends with a stream synchronisation)
+        std::memset(init, 0, 8 * sizeof(unsigned));
+        init[0] = sit0;
+        std::memcpy(&init[2], &sf, 4);
+        AO_HIP(e, hipMemcpyAsync(e->d_ctl, init, 8 * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
+    }
     auto set_sit = [&](int i) {
-        p.sit_n = sit_idx;
-        p.sit_off = sit_idx ? static_cast<unsigned>((static_cast<uint64_t>(i) * sit_idx) % static_cast<uint64_t>(e->G)) : 0u;
+        p.ctl = oversub ? e->d_ctl : nullptr;
+        p.ctl_cur = i & 1;
+        p.live_prev = (oversub && i > 0) ? slot(i - 1) : nullptr;
+        p.row_target = row_target;
     };
-    plan_sit(rows);
-    auto slot = [&](int i) -> unsigned* { return dynamic ? e->d_live + (i % ao_engine::kLive) : nullptr; };
     // sums up the row counters of the selection launches [harvested, upto) -- each of them was followed by a network launch
     auto harvest_rows = [&](int upto) -> int {
         if (!dynamic || upto <= harvested) return 0;
         AO_HIP(e, hipMemcpyAsync(e->h_live, e->d_live, sizeof(unsigned) * ao_engine::kLive, hipMemcpyDeviceToHost, e->stream));
         AO_HIP(e, hipStreamSynchronize(e->stream));
+        static const bool row_trace = getenv("AO_ROW_TRACE") != nullptr;   // developer switch: rows asked for, launch by launch
+        if (row_trace) {
+            fprintf(stderr, "AO_ROW_TRACE %d active games, %d rows, launches %d..%d, rows asked for:", rows, cap_rows, harvested, upto - 1);
+            for (int i = harvested; i < upto; ++i) fprintf(stderr, " %u", e->h_live[i % ao_engine::kLive]);
+            fprintf(stderr, "\n");
+        }
         for (int i = harvested; i < upto; ++i) {
             const int64_t want = e->h_live[i % ao_engine::kLive];
             e->rs_rows_live += std::min<int64_t>(want, cap_rows);
@@ -832,7 +872,7 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     if (oversub && sit_idx > 0) {
         // a game sits out sit_idx / G of the launches: that many more launches before anyone can be done
         const int planned = static_cast<int>(std::ceil(static_cast<double>(lt_sims) * e->G / (e->G - sit_idx))) - lt_sims;
-        for (int k = 0; k < planned - 1 && rc == 0; ++k) rc = one_sim();
+        for (int k = 0; k < planned - 8 && rc == 0; ++k) rc = one_sim();   // (a few short: the deficit rounds below find out exactly)
         if (rc) return rc;
     }
     if (oversub) {
@@ -860,10 +900,6 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
             }
             if (mx == 0 || bad || sum == last_sum) break;   // done / a per-game error (reported by ao_end_move) / no progress
             last_sum = sum;
-            int unfinished = 0;
-            for (int g = 0; g < G; ++g)
-                if (e->active[g] && h_target[g] > h_done[g]) ++unfinished;
-            plan_sit(unfinished);
             const int extra = std::max<int64_t>(mx, (sum + cap_rows - 1) / cap_rows);
             for (int k = 0; k < extra && rc == 0; ++k) rc = one_sim();
             if (rc) return rc;

@@ -97,7 +97,12 @@ struct TreeParams {
                           // needs the network takes the next row with one returning atomic; terminal leaves take none (the
                           // reference evaluates them and throws the result away, agents.py:171-178,216-221 -- SURVEY Q9), so the
                           // trunk sees live rows only: 11 - 19 % fewer with a trained network. The trunk kernels read the same word.
-    unsigned sit_n, sit_off;  // over-subscription: the games g with (g + sit_off) mod G < sit_n start no descent in this launch
+    // Over-subscription (more games than rows per simulation): a window of the game indices sits out every launch -- the games g
+    // with (g + sit_off) mod G < sit_n start no descent -- and moves on by its own length, so every game sits out equally often.
+    // The window's size follows the DEMAND: a controller on the device (tree_device.hpp, sit_window) reads the rows the previous
+    // launch was asked for and steers towards row_target (a little below row_cap). ctl: [2][4] words, slot (launch & 1) holds
+    // this launch's {sit_n, sit_off, sit as float bits}; null = nobody sits out.
+    unsigned* ctl; int ctl_cur; const unsigned* live_prev; unsigned row_target;
     unsigned row_cap;     // rows one simulation may hand out (the evaluation batch the trunk is launched for); a game that finds
                           // them taken waits for the next launch (LS_WAIT): more games than rows = over-subscription
     const float* policy;  // [G][A]

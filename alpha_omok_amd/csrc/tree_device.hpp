@@ -484,6 +484,30 @@ struct TakeRowWG {
         return (need && r < cap) ? static_cast<int>(r) : -1;
     }
 };
+// The sit-out window of this launch (TreeParams::ctl) -- and, by ONE thread of the grid, the next launch's: an integrator on
+// (rows the previous launch was asked for - row_target). The demand of launch i-1 answers the window of launch i-1 and sets the
+// window of launch i+1: z^2 - z + gain * a = 0 with a = rows asked per game that does not sit out (~0.9) -- gain 0.3 settles in a
+// handful of launches without ringing. When the games run out at the end of a move the demand falls and the window closes by itself.
+__device__ __forceinline__ void sit_window(const TreeParams& p, unsigned& sit_n, unsigned& sit_off) {
+    sit_n = sit_off = 0u;
+    if (!p.ctl) return;
+    const unsigned* cur = p.ctl + 4 * p.ctl_cur;
+    sit_n = cur[0];
+    sit_off = cur[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = __uint_as_float(cur[2]);
+        if (p.live_prev) s += 0.3f * (static_cast<float>(*p.live_prev) - static_cast<float>(p.row_target));
+        s = s < 0.f ? 0.f : s;
+        s = s > static_cast<float>(p.G - 1) ? static_cast<float>(p.G - 1) : s;
+        unsigned* nxt = p.ctl + 4 * (p.ctl_cur ^ 1);
+        unsigned off = sit_off + sit_n;
+        off = off >= static_cast<unsigned>(p.G) ? off - static_cast<unsigned>(p.G) : off;
+        nxt[0] = static_cast<unsigned>(s + 0.5f);
+        nxt[1] = off;
+        nxt[2] = __float_as_uint(s);
+    }
+}
+
 struct TakeRowNone {   // rows are not handed out by the kernel (TreeParams::live == nullptr)
     __device__ __forceinline__ int operator()(bool) const { return -1; }
 };
@@ -491,7 +515,8 @@ struct TakeRowNone {   // rows are not handed out by the kernel (TreeParams::liv
 // `exists` false: a wave of the workgroup beyond the last game -- it only keeps the row hand-out's barrier company.
 template <int NCH, class TakeRow = TakeRowNone>
 __device__ __forceinline__ void select_game(const TreeParams& p, const int g, uint32_t* s_mt /*[624]*/, uint8_t* lds_bits = nullptr,
-                                            const GameHdr* hdr = nullptr, const TakeRow& take = TakeRow(), const bool exists = true) {
+                                            const GameHdr* hdr = nullptr, const TakeRow& take = TakeRow(), const bool exists = true,
+                                            const unsigned sit_n = 0u, const unsigned sit_off = 0u) {
     const int lane = lane_id();
     AO_TT(3);
     if (!exists) { if (p.live) (void)take(false); return; }
@@ -508,14 +533,14 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     int mode = 2;
     if (!is_active || done >= target) mode = 0;
     else if (prev == LS_WAIT || prev == LS_WAIT_ROOT) mode = 1;
-    else if (p.sit_n > 0) {
+    else if (sit_n > 0) {
         // over-subscribed (more games than rows per simulation): this launch's share of the games sits out -- a window of
         // game indices that moves on by its own length with every launch, so every game sits out equally often and all of them
         // reach their simulation count within a launch or two of each other. (Who finds the batch full is NOT left to the order
         // of arrival: the deepest descents arrive last, every time.)
-        unsigned k = static_cast<unsigned>(g) + p.sit_off;
+        unsigned k = static_cast<unsigned>(g) + sit_off;
         k = k >= static_cast<unsigned>(p.G) ? k - static_cast<unsigned>(p.G) : k;
-        if (k < p.sit_n) mode = 3;
+        if (k < sit_n) mode = 3;
     }
     if (mode == 0 || mode == 3) {
         if (lane == 0) p.leaf_status[g] = LS_IDLE;

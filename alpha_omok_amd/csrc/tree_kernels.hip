@@ -26,7 +26,9 @@ namespace ao {
 template <int NCH>
 __global__ __launch_bounds__(64) void k_select(TreeParams p) {
     __shared__ uint32_t s_mt[624];
-    select_game<NCH>(p, blockIdx.x, s_mt, nullptr, nullptr, TakeRowWave{p.live, p.row_cap});
+    unsigned sit_n, sit_off;
+    sit_window(p, sit_n, sit_off);
+    select_game<NCH>(p, blockIdx.x, s_mt, nullptr, nullptr, TakeRowWave{p.live, p.row_cap}, true, sit_n, sit_off);
 }
 
 template <int NCH>
@@ -55,13 +57,15 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     const int g = blockIdx.x * kGamesPerWG + w;
     const bool exists = g < p.G;
     if (!exists && !p.live) return;
+    unsigned sit_n, sit_off;
+    sit_window(p, sit_n, sit_off);
     AO_TT(0);
     GameHdr hdr;
     if (exists) expand_backup_game<NCH>(p, g, s_ord[w], s_prior[w], s_tab[w], &hdr);
     wsync();
     AO_TT(1);
     // (rows handed out per simulation: the waves of the workgroup meet once inside select_game, see TakeRowWG)
-    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr, TakeRowWG<kGamesPerWG>{p.live, p.row_cap, s_need}, exists);
+    select_game<NCH>(p, g, s_mt[w], nullptr, &hdr, TakeRowWG<kGamesPerWG>{p.live, p.row_cap, s_need}, exists, sit_n, sit_off);
     AO_TT(2);
 }
 

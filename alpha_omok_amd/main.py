@@ -53,7 +53,12 @@ N_EPOCHS = 1
 BATCH_SIZE = 32
 LR = 2e-4
 L2 = 0
-MAX_CONCURRENT = 4096   # games resident on one GPU at a time
+MAX_CONCURRENT = 4096   # rows of the evaluation batch = leaves evaluated per simulation (and, with OVERSUBSCRIBE = 1, games resident on one GPU)
+OVERSUBSCRIBE = 1.0     # configure(oversubscribe=): game slots per row. 1.25 = 5120 resident games on 4096 rows: with a trained network
+                        # 11 - 19 % of all leaves are terminal and take no row (the tree kernel hands the rows out per simulation), so
+                        # 4096 games leave that share of the trunk's batch empty; the extra games fill it (ao_set_row_cap)
+ROWS = 'auto'           # configure(rows=): 'static' = batch rows packed per move by the host; 'dynamic' = handed out per simulation by the
+                        # tree kernel (terminal leaves take none); 'auto' = dynamic once a search met >= 3 % terminal leaves, or over-subscribed
 GAMES_PER_ITER = None   # run(): games of every iteration after the first (None: the reference's ONE game -- per rank)
 TRAIN_STEPS = None      # train(): mini-batches per pass (None: the reference's len(cur_memory), main.py:263-264)
 
@@ -79,14 +84,17 @@ trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since 
 # search shape, cumulative since configure(): PUCT levels walked, exact-tie draws, terminal leaves, evaluated leaves over all
 # simulations of all searches (levels / (evaluated + terminal) = mean selection depth)
 search_totals = {'levels': 0, 'ties': 0, 'terminal': 0, 'evaluated': 0, 'searches': 0}
-CARRY_OVER = False           # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
+CARRY_OVER = None            # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
+                             # (None = automatic: on inside run() when GAMES_PER_ITER is set, off otherwise)
 CARRY_CALLS = 2              # ... of at most this many calls ahead
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
+_terminal_share = 0.0        # terminal leaves / simulations of the last search (drives ROWS = 'auto')
+_carry_auto = False          # run() with GAMES_PER_ITER set and CARRY_OVER None
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
               model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
-              carry_over=None):
+              carry_over=None, oversubscribe=None, rows=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
     node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 40 % of the HBM
     holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
@@ -152,8 +160,33 @@ def _get_engine(games):
             _trim_base[1] += t
             _engine.close()
         _trim_seen[0] = 0
-        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device, node_cap=NODE_CAP)
+        node_cap = NODE_CAP
+        if node_cap == 0 and games > MAX_CONCURRENT:
+            # more trees than the library's default arena rule plans for (40 % of the HBM for MAX_CONCURRENT-like counts): half of
+            # the HBM for them, at most 16 x (sims + 1) nodes each
+            import torch
+            total = torch.cuda.mem_get_info(Agent._device)[1]
+            A = BOARD_SIZE * BOARD_SIZE
+            rec = (25 * ((A + 15) // 16 * 16) + 80 + 127) // 128 * 128
+            node_cap = int(max(4 * (N_MCTS + 1), min(16 * (N_MCTS + 1), 0.5 * total / (2.0 * games * rec))))
+        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device, node_cap=node_cap)
     return _engine
+
+
+def _slots(episodes_available):
+    """Game slots of the self-play engine: OVERSUBSCRIBE x MAX_CONCURRENT, never more than there are episodes to play."""
+    return int(min(episodes_available, max(1, int(round(MAX_CONCURRENT * OVERSUBSCRIBE)))))
+
+
+def _set_rows(eng):
+    """Before every search: how the evaluation batch gets its rows (ao_set_row_cap; see ROWS). Over-subscribed engines always
+    hand them out per simulation -- MAX_CONCURRENT of them."""
+    if eng.G > MAX_CONCURRENT or ROWS == 'dynamic' or (ROWS == 'auto' and _terminal_share >= 0.03):
+        cap = MAX_CONCURRENT
+    else:
+        cap = 0
+    if getattr(eng, "row_cap", 0) != cap:
+        eng.set_row_cap(cap)
 
 
 def release_engine():
@@ -177,10 +210,12 @@ class TreeTrimmed(RuntimeError):
 
 def _count_search(eng):
     """Adds the last search's shape counters (ao_search_stats: per move, summed over its games) to search_totals."""
+    global _terminal_share
     st = eng.search_stats()
     for k in ('levels', 'ties', 'terminal', 'evaluated'):
         search_totals[k] += st[k]
     search_totals['searches'] += 1
+    _terminal_share = st['terminal'] / max(st['terminal'] + st['evaluated'], 1)
 
 
 def _check_trim(eng):
@@ -206,7 +241,7 @@ def _play_episodes(episodes, use_global, seed_of):
     _pool = None                                          # (the engine is reset below: nothing stays in flight)
     E = len(episodes)
     A = BOARD_SIZE * BOARD_SIZE
-    G = min(E, MAX_CONCURRENT)
+    G = _slots(E)
     eng = _get_engine(G)
     eng.reset()
     slot_row = np.full(G, -1, np.int64)                   # row (position in `episodes`) played on each slot
@@ -229,6 +264,7 @@ def _play_episodes(episodes, use_global, seed_of):
     while active.any():
         tau = (ply < TAU_THRES).astype(np.int8)           # main.py:150-153
         t_search = time.perf_counter()
+        _set_rows(eng)
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
         _count_search(eng)
         act, win = eng.play()                             # utils.get_action + env.step
@@ -310,7 +346,7 @@ def _play_carry(first_episode, n_call, rank, world):
     global _pool
     A = BOARD_SIZE * BOARD_SIZE
     shard = parallel.shard_games(n_call, rank, world)
-    G = min(len(shard), MAX_CONCURRENT)
+    G = _slots(len(shard) * (1 + CARRY_CALLS))            # (later calls' episodes may fill what this call's leave free)
     eng = _get_engine(G)
     pool = _pool
     if pool is None or pool.eng is not eng or (pool.n_call, pool.rank, pool.world, pool.expect) != (n_call, rank, world, first_episode):
@@ -349,6 +385,7 @@ def _play_carry(first_episode, n_call, rank, world):
             raise RuntimeError("carry-over self-play: episodes %r are neither in flight nor finished" % sorted(todo)[:8])
         tau = (pool.ply < TAU_THRES).astype(np.int8)      # main.py:150-153
         t_search = time.perf_counter()
+        _set_rows(eng)
         pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=pool.active)
         _count_search(eng)
         act, win = eng.play()
@@ -425,7 +462,7 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
             ep_of = np.concatenate([np.full(p[3].shape[0], i, np.int64) for i, p in enumerate(parts)])
             ply_of = np.concatenate([p[4] for p in parts])
             pis = np.concatenate([p[5] for p in parts])
-        elif CARRY_OVER:
+        elif CARRY_OVER or (CARRY_OVER is None and _carry_auto):
             if seeds is not None:
                 raise ValueError("carry-over self-play starts episodes of later calls: their seeds are SEED + episode number, "
                                  "an explicit seeds= list cannot be honoured")
@@ -437,7 +474,12 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         # the episode numbering is where it was -- a retry plays the same episodes with the same seeds -- and the
         # carry-over pool is dropped (its finished-but-undelivered episodes and pi histories would otherwise stay in
         # it forever and the later calls' games would keep occupying slots)
-        _episodes_played = first_episode
+        # -- with ONE process. Under torch.distributed the other ranks have already advanced past these episode numbers (the
+        # counter must stay identical on every rank), so a rank that catches the exception and carries on keeps the advanced
+        # counter: the failed call's episodes are skipped, not replayed under seeds the others have left behind. (And in
+        # single_stream mode the global np.random stream has moved on: a retry is a new draw, not a replay.)
+        if world == 1:
+            _episodes_played = first_episode
         _pool = None
         raise
 
@@ -678,8 +720,16 @@ def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, sa
         logging.warning(' ' * 20 + '  {:2} Iteration  '.format(n_iter) + ' ' * 20)
         logging.warning('=' * 58)
         if n_iter > 0:
-            # the reference's one game -- on every GPU; GAMES_PER_ITER games (over all ranks) when set
-            self_play(parallel.world()[1] if GAMES_PER_ITER is None else int(GAMES_PER_ITER))
+            # the reference's one game -- on every GPU; GAMES_PER_ITER games (over all ranks) when set. With thousands of games
+            # per iteration the engine is kept full ACROSS iterations (carry-over, see configure) unless carry_over=False was
+            # asked for: the price is the reference's strict alternation -- an episode may have been started under the
+            # weights of up to CARRY_CALLS iterations ago.
+            global _carry_auto
+            _carry_auto = GAMES_PER_ITER is not None
+            try:
+                self_play(parallel.world()[1] if GAMES_PER_ITER is None else int(GAMES_PER_ITER))
+            finally:
+                _carry_auto = False
             train(N_EPOCHS, n_iter)
         else:
             self_play(n_first)

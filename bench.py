@@ -78,30 +78,39 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
     net = PVNet(n_block, 5, planes, board)
     net.load_state_dict(state_dict)
     net.eval()
-    # batch-1 convolutions do not scale to a whole server socket: pick the fastest intra-op thread
-    # count from a short calibration (the reference just uses torch's default)
-    probe = torch.zeros((1, 5, board, board))
-    best = (None, 1e9)
-    for nt in sorted({1, 4, 8, 16, 32, min(64, os.cpu_count() or 1)}):
-        if nt > (os.cpu_count() or 1):
-            continue
-        torch.set_num_threads(nt)
-        with torch.no_grad():
-            for _ in range(3):
-                net(probe)
-            t0 = time.perf_counter()
-            for _ in range(20):
-                net(probe)
-            dt = (time.perf_counter() - t0) / 20
-        if dt < best[1]:
-            best = (nt, dt)
-    torch.set_num_threads(best[0])
-    cores = best[0]
-
     def ev(moves, planes_, sim):
         with torch.no_grad():
             p, v = net(torch.from_numpy(planes_[None].copy()))
         return p[0].numpy(), np.float32(v[0].item())
+
+    # batch-1 convolutions do not scale to a whole server socket: the intra-op thread count is picked by a calibration on the
+    # REAL loop -- per candidate two 40-simulation searches (oracle tree + callback + forward), after one untimed search -- and
+    # every candidate's rate is reported. (Round 4 calibrated on 20 bare forwards: the pick flipped between 8, 16 and 32 threads
+    # from run to run and the baseline swung 2 x with it.)
+    calib_sims = min(sims, 40)
+    calibration = {}
+    best = (1, 0.0)
+    for nt in (1, 2, 4, 8, 16, 32):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        cal = O.Agent(board, calib_sims, 5, noise=True, evaluator=ev)
+        cal.seed(0)
+        cal.get_pi((0,), 1)
+        cal.reset()
+        t0 = time.perf_counter()
+        n_done = 0
+        root = (0,)
+        for _ in range(2):
+            pi, vis, pol = cal.get_pi(root, 1)
+            n_done += calib_sims
+            root = root + (int(cal.rng.choice_p(pi)),)
+        rate = n_done / (time.perf_counter() - t0)
+        calibration[str(nt)] = round(rate, 1)
+        if rate > best[1]:
+            best = (nt, rate)
+    torch.set_num_threads(best[0])
+    cores = best[0]
 
     ag = O.Agent(board, sims, 5, noise=True, evaluator=ev)
     ag.seed(0)
@@ -120,6 +129,7 @@ def cpu_baseline(board, sims, n_block, planes, state_dict, budget_s):
     dt = time.perf_counter() - t0
     nproc, cpu_model = host_cpu()
     return dict(value=moves / dt, unit="move-decisions/s", cores=cores, kind="port", host_nproc=nproc, host_cpu_model=cpu_model,
+                calibration={"unit": "simulations/s of two %d-simulation searches per intra-op thread count" % calib_sims, "threads": calibration},
                 sample="%d move decisions of one 9x9 game, %d sims each, oracle C tree + PyTorch-CPU "
                        "PVNet at batch 1, %d threads, %.1f s" % (moves, sims, cores, dt))
 
@@ -303,13 +313,16 @@ class TrainStep:
         # the samples all ranks put behind a step, agreed ONCE (the shards do not change during the bench): the per-step
         # gradient all-reduce then reads nothing back from the device (parallel.allreduce_gradients, `total`)
         from alpha_omok_amd import parallel
-        self.total = parallel.agree_sums([min(M.BATCH_SIZE, len(M.rep_memory))], torch.device("cuda", local))[0] if world > 1 else None
+        # (the batch size is frozen with the divisor: the shards GROW during the timed loop -- self-play appends -- and a rank that
+        # started below BATCH_SIZE would otherwise draw larger batches than the agreed total accounts for)
+        self.batch_n = min(M.BATCH_SIZE, len(M.rep_memory))
+        self.total = parallel.agree_sums([self.batch_n], torch.device("cuda", local))[0] if world > 1 else None
 
     def step(self, record):
         M = self.M
         t0 = time.perf_counter()
         n = len(M.rep_memory)
-        batch = self.random.sample(range(n), min(M.BATCH_SIZE, n))
+        batch = self.random.sample(range(n), min(self.batch_n, n))
         out = M.train_batch(batch, self.total)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -367,78 +380,114 @@ TIMING_STRIDE = 8
 TRAINED_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_trained_9x9_4block.pt")
 
 
-def trained_net_bench(args, local, path, steps=8, warm_plies=8):
+def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.25):
     """The headline workload with a TRAINED network (a checkpoint of tools/train_omok.py: this engine's own self-play +
     main.train on the MI355X) instead of random-init weights: sharp priors, so the searches go deep, meet terminal leaves
     and keep most of the tree from move to move -- the regime the tree kernels exist for. Fresh engine, `warm_plies`
-    untimed move decisions (the tau switch at ply 6 included), then `steps` timed ones with refills."""
+    untimed move decisions (the tau switch at ply 6 included), then `steps` timed ones with refills.
+
+    Two runs on the same box, back to back:
+      * `static_rows`: G games, the evaluation batch packed per move by the host (rounds 3 - 4): a game whose leaf is terminal
+        keeps its stale row in the batch, so 11 - 19 % of the trunk's rows are junk with this network;
+      * the result proper: `oversubscribe` x G games on the same G rows per simulation, handed out by the tree kernel per
+        simulation (ao_set_row_cap(G): terminal leaves take none; a share of the games sits out each launch in turn) -- the
+        trunk launch is the same 256 groups, but every row is a live leaf. A step is still one move decision of every game."""
     from alpha_omok_amd.engine import Engine
     from alpha_omok_amd.pvnet import PVNet
     B, S, G = args.board, args.sims, args.games
     model = PVNet(args.blocks, 5, args.planes, B)
-    model.load_state_dict(torch.load(path, map_location="cpu"))
+    model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
     model.eval()
     net = model.to_native(local)
-    eng = Engine(B, S, 5, games=G, noise=True, device=local)
-    eng.seed_all(np.arange(7 * G, 8 * G, dtype=np.uint32))
-    ply = np.zeros(G, np.int64)
-    nxt = [9 * G]
-    c = dict(levels=0, evaluated=0, terminal=0, games=0)
-
-    def one(count):
-        eng.search(net, tau=(ply < 6).astype(np.int8))
-        st = eng.search_stats()
-        act, win = eng.play()
-        ply[:] += 1
-        done = win != 0
-        if count:
-            for k in ("levels", "evaluated", "terminal"):
-                c[k] += st[k]
-            c["games"] += int(done.sum())
-        if done.any():
-            eng.reset(done.astype(np.uint8))
-            for g in np.nonzero(done)[0]:
-                eng.seed(int(g), nxt[0])
-                nxt[0] += 1
-            ply[done] = 0
-
-    for _ in range(warm_plies):
-        one(False)
-    eng.tree_timing(TIMING_STRIDE)
-    net.conv_timing(TIMING_STRIDE)
-    eng.sync()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one(True)
-    eng.sync()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    conv_ms, conv_n = net.conv_timing(False)
-    tree_ms, tree_n = eng.tree_timing(False)
-    sims_total = max(c["evaluated"] + c["terminal"], 1)
-    d_bar = c["levels"] / sims_total
     A_ = B * B
-    tree_bytes = G * (A_ * (16.0 * d_bar + 44.0) + 24.0 * (d_bar + 1.0) + 4.0)   # SURVEY.md 8(d), C = 5
-    tree_avg = tree_ms / max(tree_n, 1)
-    dropped, trimmed = eng.trim_stats()
-    ev, evg = eng.fp16_range_events()
-    kname, f_launch = net.dominant_kernel(G)
-    r = {"weights": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))),
-         "workload": "same games / sims / slots as the headline, network = the committed checkpoint trained by this engine "
-                     "(tools/train_omok.py); plies %d-%d timed" % (warm_plies, warm_plies + steps - 1),
-         "value": G * steps / dt, "unit": "move-decisions/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-         "mean_select_depth": d_bar, "terminal_leaf_fraction": c["terminal"] / sims_total, "games_finished": c["games"],
-         "trunk_kernel": kname.split(" (")[0], "trunk_avg_launch_ms": conv_ms / max(conv_n, 1),
-         "trunk_time_share": conv_ms * TIMING_STRIDE * 1e-3 / dt,
-         "roofline_tree": {"kernel": "k_expand_select", "avg_launch_ms": tree_avg, "launches_timed": tree_n,
-                           "algorithmic_bytes_per_launch": tree_bytes,
-                           "achieved": tree_bytes / (tree_avg * 1e-3) / 1e9 if tree_n else 0.0, "unit": "GB/s", "peak": 8000.0,
-                           "frac": tree_bytes / (tree_avg * 1e-3) / 1e9 / 8000.0 if tree_n else 0.0,
-                           "time_share": tree_ms * TIMING_STRIDE * 1e-3 / dt},
-         "node_cap": eng.node_cap()[0], "arena_trims": {"subtrees_dropped": dropped, "reroots_trimmed": trimmed},
-         "fp16_range_events": ev}
-    eng.close()
+
+    def run(games, row_cap):
+        node_cap = 0
+        if games > G:   # more trees than the default arena rule plans for: half of the HBM for them, at most 16 x (sims + 1) nodes each
+            total = torch.cuda.mem_get_info(local)[1]
+            rec = (25 * ((A_ + 15) // 16 * 16) + 80 + 127) // 128 * 128
+            node_cap = int(max(4 * (S + 1), min(16 * (S + 1), 0.5 * total / (2.0 * games * rec))))
+        eng = Engine(B, S, 5, games=games, noise=True, device=local, node_cap=node_cap)
+        if row_cap:
+            eng.set_row_cap(row_cap)
+        eng.seed_all(np.arange(7 * G, 7 * G + games, dtype=np.uint32))
+        ply = np.zeros(games, np.int64)
+        nxt = [9 * G]
+        c = dict(levels=0, evaluated=0, terminal=0, games=0)
+
+        def one(count):
+            eng.search(net, tau=(ply < 6).astype(np.int8))
+            st = eng.search_stats()
+            act, win = eng.play()
+            ply[:] += 1
+            done = win != 0
+            if count:
+                for k in ("levels", "evaluated", "terminal"):
+                    c[k] += st[k]
+                c["games"] += int(done.sum())
+            if done.any():
+                eng.reset(done.astype(np.uint8))
+                for g in np.nonzero(done)[0]:
+                    eng.seed(int(g), nxt[0])
+                    nxt[0] += 1
+                ply[done] = 0
+
+        for _ in range(warm_plies):
+            one(False)
+        eng.tree_timing(TIMING_STRIDE)
+        net.conv_timing(TIMING_STRIDE)
+        rs0 = eng.row_stats()
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one(True)
+        eng.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        conv_ms, conv_n = net.conv_timing(False)
+        tree_ms, tree_n = eng.tree_timing(False)
+        rs1 = eng.row_stats()
+        sims_total = max(c["evaluated"] + c["terminal"], 1)
+        d_bar = c["levels"] / sims_total
+        tree_bytes = games * (A_ * (16.0 * d_bar + 44.0) + 24.0 * (d_bar + 1.0) + 4.0)   # SURVEY.md 8(d), C = 5
+        tree_avg = tree_ms / max(tree_n, 1)
+        dropped, trimmed = eng.trim_stats()
+        ev, evg = eng.fp16_range_events()
+        kname, f_launch = net.dominant_kernel(row_cap or games)
+        launches = rs1["launches"] - rs0["launches"]
+        r = {"games": games, "rows_per_simulation": row_cap or games,
+             "rows": "handed out per simulation by the tree kernel (ao_set_row_cap)" if row_cap else "packed per move by the host",
+             "value": games * steps / dt, "unit": "move-decisions/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+             "mean_select_depth": d_bar, "terminal_leaf_fraction": c["terminal"] / sims_total, "games_finished": c["games"],
+             # rows the trunk really evaluated per simulation of a game: 1 with the per-move packing (terminal leaves keep a stale
+             # row), 1 - terminal share when rows are handed out per simulation
+             "rows_evaluated_per_simulation": (rs1["rows_live"] - rs0["rows_live"]) / sims_total if row_cap else 1.0,
+             "trunk_kernel": kname.split(" (")[0], "trunk_avg_launch_ms": conv_ms / max(conv_n, 1),
+             "trunk_time_share": conv_ms * TIMING_STRIDE * 1e-3 / dt,
+             "roofline_tree": {"kernel": "k_expand_select", "avg_launch_ms": tree_avg, "launches_timed": tree_n,
+                               "algorithmic_bytes_per_launch": tree_bytes,
+                               "achieved": tree_bytes / (tree_avg * 1e-3) / 1e9 if tree_n else 0.0, "unit": "GB/s", "peak": 8000.0,
+                               "frac": tree_bytes / (tree_avg * 1e-3) / 1e9 / 8000.0 if tree_n else 0.0,
+                               "time_share": tree_ms * TIMING_STRIDE * 1e-3 / dt},
+             "node_cap": eng.node_cap()[0], "arena_trims": {"subtrees_dropped": dropped, "reroots_trimmed": trimmed},
+             "fp16_range_events": ev}
+        if row_cap:
+            r["network_launches_per_move"] = launches / max(steps, 1)
+            r["batch_fill"] = (rs1["rows_live"] - rs0["rows_live"]) / max(rs1["rows_launched"] - rs0["rows_launched"], 1)
+            r["leaves_that_waited_a_launch"] = rs1["waits"] - rs0["waits"]
+        eng.close()
+        return r
+
+    static = run(G, 0)
+    over = run(int(round(G * oversubscribe / 256.0)) * 256, G) if oversubscribe and oversubscribe > 1.0 else None
+    r = dict(over if over else static)
+    r["weights"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    r["workload"] = ("the headline's sims / rows per simulation, network = the committed checkpoint trained by this engine "
+                     "(tools/train_omok.py); plies %d-%d timed" % (warm_plies, warm_plies + steps - 1))
+    if over:
+        r["static_rows"] = static
+        r["vs_static_rows"] = over["value"] / static["value"]
     net.close()
     return r
 
@@ -494,6 +543,8 @@ def main():
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the one-process-per-hardware-thread CPU sample")
     ap.add_argument("--cpu-all-cores-budget", type=float, default=6.0, help="seconds per process of the all-cores sample")
     ap.add_argument("--trained-weights", default=TRAINED_CKPT, help="state_dict of a trained 9x9 / 4-block / 128-plane PVNet for the `trained_net` leg")
+    ap.add_argument("--oversubscribe", type=float, default=1.25, help="`trained_net` leg: games per row of the evaluation batch (1.25: 5120 games on "
+                    "the 4096 rows per simulation the tree kernel hands out; 1: the per-move packing only)")
     ap.add_argument("--no-trained-net", action="store_true", help="skip the `trained_net` leg (the headline workload with trained weights)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -598,6 +649,13 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    # what the collective library itself saw during the timed run: the group's size and backend, and the sum over the group of one
+    # 1 per rank (the reduction just above ran on the same group) -- so that an N-GPU line proves RCCL ("nccl") had N ranks
+    rccl_ranks = None
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_in_allreduce": int(round(float(ones.item())))}
     total_moves = world * G * args.steps
     value = total_moves / dt_max
     train_report = trainer.report(dist, dev, dt_max / args.steps * 1e3) if trainer is not None else None  # (collective)
@@ -630,6 +688,7 @@ def main():
             "value": value,
             "unit": "move-decisions/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
@@ -752,7 +811,7 @@ def main():
         eng.close()
         if world == 1 and not args.no_trained_net and os.path.exists(args.trained_weights) and (B, args.blocks, args.planes) == (9, 4, 128):
             try:
-                out["trained_net"] = trained_net_bench(args, local, args.trained_weights)
+                out["trained_net"] = trained_net_bench(args, local, args.trained_weights, oversubscribe=args.oversubscribe)
             except Exception as e:
                 out["trained_net"] = {"value": None, "error": repr(e)}
         if world == 1 and G > 1 and not args.no_single_game:
