@@ -65,6 +65,7 @@ TRAIN_STEPS = None      # train(): mini-batches per pass (None: the reference's 
 rep_memory = deque(maxlen=MEMORY_SIZE)
 cur_memory = deque()
 step = 0
+skipped_steps = 0       # train_batch: mini-batches whose loss was not finite (one process only; see train_batch)
 start_iter = 0
 total_epoch = 0
 result = {'Black': 0, 'White': 0, 'Draw': 0}
@@ -107,10 +108,25 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     of idling while the call's longest games run down; every call still returns exactly its own episodes' samples, in
     episode order. The price is the reference's strict alternation (main.py:250-262: all of an iteration's games are played
     by that iteration's network): an episode may have been started -- and partly played -- with the weights of an earlier
-    iteration. Off by default."""
+    iteration. Off by default for direct self_play calls; run() turns it on when GAMES_PER_ITER is set (thousands of games per
+    iteration: the engine would otherwise run down to a handful of games at the end of every call) unless carry_over=False.
+    oversubscribe: game slots per row of the evaluation batch (MAX_CONCURRENT rows). 1.25 keeps 5120 games resident on 4096
+    rows: the tree kernel hands out the rows per simulation, terminal leaves (11 - 19 % with a trained network) take none,
+    and the extra games fill what they leave -- every game still runs the reference's strictly sequential search.
+    rows: 'static' / 'dynamic' / 'auto' (see ROWS)."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
-    global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP, CARRY_OVER, _pool
-    CARRY_OVER = CARRY_OVER if carry_over is None else bool(carry_over)
+    global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP, CARRY_OVER, _pool, OVERSUBSCRIBE, ROWS, _terminal_share
+    if carry_over is not None:
+        CARRY_OVER = bool(carry_over)
+    if oversubscribe is not None:
+        if not 1.0 <= float(oversubscribe) <= 2.0:
+            raise ValueError("oversubscribe must be in [1, 2]")
+        OVERSUBSCRIBE = float(oversubscribe)
+    if rows is not None:
+        if rows not in ('auto', 'static', 'dynamic'):
+            raise ValueError("rows must be 'auto', 'static' or 'dynamic'")
+        ROWS = rows
+    _terminal_share = 0.0
     _pool = None
     STRICT = STRICT if strict is None else bool(strict)
     NODE_CAP = NODE_CAP if node_cap is None else int(node_cap)
@@ -534,6 +550,16 @@ def train_batch(batch, total=None):
     # each rank's gradient counts for the samples behind it (a shard that ran short contributes a partial batch)
     _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0, weight=len(batch), total=total)
     if contributors == 0:
+        return None
+    if len(batch) > 0 and parallel.world()[1] == 1 and not bool(torch.isfinite(loss)):
+        # -(pi * p.log()) is the reference's loss (main.py:296-299) and it is -inf * pi as soon as the softmax underflows to an
+        # exact 0 on a move the search visited; the reference would write NaN into every weight and carry on. One process:
+        # the step is skipped and counted (skipped_steps), the weights stay what they were. (Under torch.distributed the ranks'
+        # losses differ and the step stays enqueue-only: unguarded, as in the reference.)
+        global skipped_steps
+        skipped_steps += 1
+        logging.warning('train_batch: non-finite loss (%r), optimiser step skipped (%d so far)', float(loss), skipped_steps)
+        optimizer.zero_grad()
         return None
     optimizer.step()
     step += 1

@@ -153,7 +153,8 @@ def test_fused_search_trained_net_through_the_planner_boundaries_vs_oracle(oracl
     net.close()
 
 
-def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulation_rows():
+@pytest.mark.parametrize("G,PLIES,CAP,mode", [(1024, 13, 640, 6), (4096, 9, 3072, 0)])
+def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulation_rows(G, PLIES, CAP, mode):
     """One arithmetic for every batch size (ao_net_set_mode 6) makes a game's evaluations independent of who else is in the
     batch, so FOUR ways of running the same 1024 games must agree for EVERY game at every ply, bit for bit:
       A  ao_search, rows packed per move by the host (rounds 3 - 4),
@@ -161,17 +162,19 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
       C  ao_search, rows handed out per simulation by the tree kernel (ao_set_row_cap(G): terminal leaves take no row),
       D  the same over-subscribed (640 rows for up to 1024 games: a share of the games sits out each launch, leaves that find
          the batch full wait one launch; more launches per move).
-    13 plies of the trained network with games ending and being retired."""
+    13 plies of the trained network with games ending and being retired.
+    Second case: 4096 games in the default mode, where all four run the RESIDENT trunk (k_trunk16hb / k_trunk16h, >= 192 groups;
+    its result for a board does not depend on the board's row or neighbours either): the kernel of the headline, reading the live-row
+    count (C, D: 3072 rows = 192 groups for 4096 games)."""
     import torch
     from alpha_omok_amd.engine import Engine, Net
-    G, PLIES, CAP = 1024, 13, 640
     net = Net(2, 5, 128, B, 0)
     net.load_state_dict(_trained_state_dict())
-    net.set_mode(6)
+    net.set_mode(mode)
     seeds = np.arange(52000, 52000 + G, dtype=np.uint32)
     engs = {}
     for name in "ABCD":
-        engs[name] = Engine(B, S, 5, games=G, noise=True, node_cap=8 * (S + 1))
+        engs[name] = Engine(B, S, 5, games=G, noise=True, node_cap=(8 if G <= 1024 else 5) * (S + 1))   # (four engines side by side)
         engs[name].seed_all(seeds)
     engs["C"].set_row_cap(G)
     engs["D"].set_row_cap(CAP)
@@ -181,11 +184,13 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
     terminal = 0
     sims_total = 0
     for t in range(PLIES):
-        if t in _KEEP_AT_PLY:
+        if G == 1024 and t in _KEEP_AT_PLY:
             _retire(alive, _KEEP_AT_PLY[t], set())
         if not alive.any():
             break
         on = alive != 0
+        if mode == 0:
+            assert int(on.sum()) >= 3072 + 16, "the resident trunk needs 192 groups: shorten the test"
         tau = np.full(G, 1 if t < 6 else 0, np.int8)
         out = {}
         for name in "ACD":

@@ -39,7 +39,15 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--l2", type=float, default=1e-4)
     ap.add_argument("--memory", type=int, default=2_000_000, help="replay entries (8 per sample)")
-    ap.add_argument("--carry-over", action="store_true")
+    ap.add_argument("--no-carry-over", action="store_true",
+                    help="play every iteration's games to the end before training (the reference's strict alternation, main.py:250-262). "
+                         "Default: carry-over -- the engine stays full across iterations, a slot whose game ends starts an episode of the "
+                         "NEXT iteration(s), so an episode may be played partly under the weights of up to two iterations ago (the usual "
+                         "asynchronous-actor trade; alpha_omok_amd.main.configure)")
+    ap.add_argument("--oversubscribe", type=float, default=1.25,
+                    help="game slots per row of the 4096-row evaluation batch (main.configure: 1.25 = 5120 resident games; terminal leaves "
+                         "take no row, the extra games fill what they leave). 1 = as many games as rows")
+    ap.add_argument("--rows", default="auto", choices=("auto", "static", "dynamic"))
     ap.add_argument("--eval-every", type=int, default=5)
     ap.add_argument("--eval-matches", type=int, default=64)
     ap.add_argument("--eval-sims", type=int, default=None)
@@ -67,7 +75,7 @@ def main():
 
     m.BATCH_SIZE, m.LR, m.L2, m.MEMORY_SIZE, m.TRAIN_STEPS = a.batch, a.lr, a.l2, a.memory, a.steps
     m.configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, out_planes=a.planes, seed=a.seed,
-                device_replay=True, carry_over=a.carry_over)
+                device_replay=True, carry_over=not a.no_carry_over, oversubscribe=a.oversubscribe, rows=a.rows)
     if a.resume:
         m.Agent.model.load_state_dict(torch.load(a.resume, map_location=m.device))
     dev = m.device
@@ -118,7 +126,7 @@ def main():
                    loss=[round(float(x), 4) for x in np.mean(np.array(losses), axis=0)] if losses else None,
                    mean_select_depth=round(d["levels"] / max(d["evaluated"] + d["terminal"], 1), 3),
                    terminal_share=round(d["terminal"] / max(d["evaluated"] + d["terminal"], 1), 4),
-                   trims=dict(m.trim_stats), node_cap=eng.node_cap()[0], fp16_range_events=ev,
+                   trims=dict(m.trim_stats), node_cap=eng.node_cap()[0], fp16_range_events=ev, slots=eng.G, rows=eng.row_stats(),
                    replay=len(m.rep_memory), games_total=games_total, moves_total=moves_total)
         emit(rec)
         m.reset_iter(m.result, m.cur_memory)
