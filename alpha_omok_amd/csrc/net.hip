@@ -23,6 +23,7 @@
 #include "net_trunk_f32.hpp"
 #include "net_trunk_h16.hpp"
 #include "net_layer_ksplit.hpp"
+#include "net_board_h16.hpp"
 #include "net_small.hpp"
 
 
@@ -76,6 +77,11 @@ struct ao_net {
     // 192 .. 512 against the per-board path / k_layer16h (profiles/r4w_row_kernel_small_batches.txt). AO_ROWK="lo,hi".
     int rowk_min = 1, rowk_max = 47;
     bool attr_r[16] = {};
+    // boards wider than 9: from this many boards on the trunk convs run as ONE launch of k_boardh (a workgroup = a board resident in
+    // LDS through all layers, cells as the MFMA N dimension: net_board_h16.hpp); below it k_layer16h spreads a group over more
+    // workgroups than there are boards. AO_BOARDK=n overrides (0 = never).
+    int boardk_min = 128;
+    bool attr_b[16] = {};
     // boards x cells up to which the per-board path is planned (boards of 4x4 .. 9x9, with k_row16hk behind it: 32 boards of 9x9 --
     // it was 96 before that kernel; AO_PERBOARD_CELLS)
     long perboard_cells = 2592;
@@ -175,6 +181,11 @@ static void timer_end(ao_net* n, int idx, hipStream_t s) {
 // that what evaluates a position -- and therefore a game's whole trajectory -- does not depend on how many other games
 // share the batch. k_layer16h's arithmetic per output element is the same for any chunking and any neighbour boards.
 static bool layers_only(const ao_net* n) { return n->mode == 6; }
+
+static bool h16_supported(const ao_net* n);
+static bool board_resident(const ao_net* n, int boards) {
+    return n->mode != 6 && n->B >= 10 && n->nb >= 1 && n->boardk_min > 0 && boards >= n->boardk_min && h16_supported(n);
+}
 
 static bool h16_supported(const ao_net* n) {
     return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
@@ -599,8 +610,44 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             if (timed) timer_end(n, idx, s);
             return 0;
         };
-        for (int l = 0; l <= 2 * n->nb; ++l)
-            if (layer(l)) return 1;
+        if (board_resident(n, boards)) {
+            // conv1 as before, then ALL trunk convs in one launch: a workgroup per board (net_board_h16.hpp)
+            if (layer(0)) return 1;
+            BoardHArgs a;
+            a.act = reinterpret_cast<uint4*>(n->act_x);
+            a.res = n->act_t;
+            a.nlayers = 1 + 2 * n->nb;
+            a.nboards = boards;
+            a.live = live; a.row_cap = row_cap;
+            for (int l = 0; l < a.nlayers; ++l) {
+                a.layers[l].wh = n->convh_wh[l];
+                a.layers[l].wl = n->convh_wl[l];
+                a.layers[l].sc = reinterpret_cast<const float4*>(n->convh_sc[l]);
+                a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
+                a.layers[l].ovf = n->d_status;
+            }
+            const dim3 grid(std::min(boards, n->num_cu)), block(512);
+            const int idx = n->timing ? timer_begin(n, s) : 0;
+            switch (n->B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W: {                                                                                                          \
+        constexpr size_t lds_ = static_cast<size_t>(W) * 8 * 1024;                                                     \
+        if (!n->attr_b[W]) {                                                                                           \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boardh<W>),                                \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            n->attr_b[W] = true;                                                                                       \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_boardh<W>), grid, block, lds_, s, a);                                                    \
+    } break;
+                AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
+#undef AO_BW_CASE
+                default: return n->fail("k_boardh: board outside 10 .. 15");
+            }
+            if (n->timing) timer_end(n, idx, s);
+        } else {
+            for (int l = 0; l <= 2 * n->nb; ++l)
+                if (layer(l)) return 1;
+        }
         NET_HIP(n, hipGetLastError());
         heads_h16 = true;   // k_head_conv<true> / k_head_fc below
     } else if (group == 16 && mode == 5) {
@@ -806,6 +853,7 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
         if (sscanf(v, "%d,%d,%d", &lo, &hi, &hi2) == 3) { n->ksplit_min = lo > 0 ? lo : 1 << 30; n->ksplit_max = hi; n->ksplit_max2 = hi2; }
     }
     if (const char* v = getenv("AO_PERBOARD_CELLS")) n->perboard_cells = atol(v);
+    if (const char* v = getenv("AO_BOARDK")) n->boardk_min = atoi(v);   // boards from which k_boardh carries the trunk of boards wider than 9 (0: never)
     if (const char* v = getenv("AO_ROWK")) {   // "lo,hi": groups that take k_row16hk ("0,-1" turns it off)
         int lo = 0, hi = -1;
         if (sscanf(v, "%d,%d", &lo, &hi) == 2) { n->rowk_min = lo; n->rowk_max = hi; }
@@ -1156,6 +1204,10 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
              "a 16-board group split over " + (four ? "four workgroups by cout pairs" : "two workgroups by cout quads") +
              ", waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
+    } else if (group == 16 && mode == 5 && board_resident(n, boards)) {
+        nm = "k_boardh<" + bw + "> (" + std::to_string(2 * n->nb) + " 3x3 convs in one launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
+             "a workgroup = one board resident in LDS through all layers, the row's cells as the MFMA N dimension, column shifts as DPP row shifts)";
+        f = 2.0 * n->nb * 2.0 * n->A * 9.0 * n->planes * n->planes * boards;
     } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (boards + 15) / 16 >= 192))) {
         nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
              "16-board groups x row chunks x column tiles)";

@@ -1,0 +1,221 @@
+// net_board_h16.hpp -- k_boardh<BW>: the trunk of ONE board resident in LDS, cells as the MFMA N dimension (round 5).
+//
+// Boards wider than 9 (15x15: BASELINE configs[4]) had no multi-layer kernel: a 16-board group's input row does not fit LDS twice,
+// so k_layer16h runs one launch per conv, every workgroup pays halo columns, a staging round trip and an epilogue per row step,
+// and the activations make a round trip through HBM per layer (model.py:13-31,97-104: 21 convs for 10 blocks). Here the
+// decomposition is turned around:
+//   * a workgroup carries ONE board through all trunk convs; the board's activations live in LDS as the two fp16 halves of the
+//     split-fp16 scheme (x = xh + xl, net_trunk_h16.hpp), rows padded to 16 cells: fragment (row, 32-channel block, half) =
+//     1 KB = one B operand of v_mfma_f32_16x16x32_f16 with the row's CELLS as N (lane = k-octet * 16 + cell holds 8 consecutive
+//     channels). 15 x 4 x 2 KB = 120 KB; the 16th cell of a row is a zero pad;
+//   * a tap's column shift dx = +-1 is a DPP row shift of the fragment's registers (a "row" of the DPP network is exactly the 16
+//     lanes of one k-octet; the pad cell / bound_ctrl supply the zeros off the board), the row shift dy = +-1 is a whole-tile
+//     shift: input row r feeds output rows r-1, r, r+1, and rows off the board are skipped tile-uniformly -- no halo, no
+//     MFMA on padding except the 16th cell (1.07 x the algorithmic MFMAs; k_layer16h<15> issues 15 x 18 / (15 x 15) = 1.2 x on its
+//     column tiles + halo);
+//   * wave w owns cout tile w (8 waves, two per SIMD) and keeps the accumulators of ALL 15 output rows (60 registers); the
+//     contraction runs slab-outermost: for each (32-channel input block, tap row) the wave has its 3 taps x {high, low} weight
+//     fragments in registers (streamed from L2 one slab ahead: every workgroup of the chip reads the same 590 KB per layer) and
+//     sweeps the board's rows -- 2 LDS reads, 4 DPP shifts and 9 MFMAs per (row, slab), no barrier inside a layer: the waves drift;
+//   * layer boundary = barrier (everyone has read the input) -> epilogue (BatchNorm, residual, ReLU, split, 8-byte LDS writes in
+//     place) -> barrier. The ResBlock input is parked as fp32 in a per-board scratch in global memory (L2-hot, 115 KB) when it is
+//     produced and read back in the epilogue of the block's second conv;
+//   * conv1 and the heads stay where they are (k_layer16h<BW, ..., KIND 1 / 2>, k_head_conv / k_head_fc): the kernel reads and
+//     writes the 16-board-group layout of the per-layer path, so `ao_net_forward` changes ONE thing -- 2 x n_block launches become one.
+// Same arithmetic family as the other split-fp16 kernels (3 products per multiply-add, fp32 accumulate, weights pre-scaled by a
+// power of two per layer); the summation order over taps / blocks differs, so results agree to fp32 rounding, not bit for bit.
+#pragma once
+
+namespace ao {
+
+struct BoardHArgs {
+    uint4* act;          // [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B: in = conv1's output, out = the trunk's output
+    float* res;          // [board][BW * BW * 128] fp32 scratch: the ResBlock input in D-operand order (see below)
+    int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0] is not used here)
+    int nboards;
+    const unsigned* live;   // live rows of this simulation's batch (net_common.hpp) or null
+    unsigned row_cap;
+    TrunkHLayer layers[kMaxTrunkLayers];
+};
+
+constexpr int kDppRowShr1 = 0x111, kDppRowShl1 = 0x101;
+template <int CTRL>
+__device__ __forceinline__ half8 dpp_shift_h8(const half8 v) {
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    u32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = static_cast<unsigned>(__builtin_amdgcn_mov_dpp(static_cast<int>(u[k]), CTRL, 0xf, 0xf, true));   // bound_ctrl: lanes without a source read 0
+    return __builtin_bit_cast(half8, r);
+}
+
+template <int BW>
+__global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
+    static_assert(BW >= 10 && BW <= 15, "rows are padded to 16 cells and need at least one zero pad");
+    constexpr int A = BW * BW;
+    constexpr int NCI = 4, NT = 8;                 // 128 channels: four 32-channel blocks, eight 16-channel cout tiles
+    constexpr int NFR = BW * NCI * 2;              // 1 KB fragments of the board
+    extern __shared__ __attribute__((aligned(16))) uint4 s_x[];   // [row][block][half][64] : NFR KB
+    const int lane = threadIdx.x & 63;
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int kq = lane >> 4, n = lane & 15;       // B operand: k-octet, cell of the row; D operand: cout quad, cell
+    const int lane16 = lane * 16;
+    unsigned nlive = static_cast<unsigned>(a.nboards);
+    if (a.live) {
+        const unsigned lv = *a.live < a.row_cap ? *a.live : a.row_cap;
+        nlive = lv < nlive ? lv : nlive;
+    }
+    // the lane's 8-byte slot inside output fragment (row, tile >> 1, half): cout quad q = kq -> k-octet (tile & 1) * 2 + (kq >> 1)
+    const int out_off = (((tile & 1) * 2 + (kq >> 1)) * 16 + n) * 16 + (kq & 1) * 8;
+    float peak = 0.f;
+    for (unsigned board = blockIdx.x; board < nlive; board += gridDim.x) {
+        const unsigned grp = board >> 4, bslot = board & 15u;
+        const char* gact = reinterpret_cast<const char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
+        float* res = a.res + static_cast<size_t>(board) * A * 128;
+        // ---- the board's activations (conv1's output) into LDS; the block input x also goes to the scratch as fp32
+        __syncthreads();   // (the previous board's write-back has read the buffer)
+#pragma unroll 1
+        for (int f = tile; f < BW * NCI; f += NT) {            // (row, block): both halves
+            const int row = f / NCI, kb = f % NCI;
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+            if (n < BW) {
+                const char* p = gact + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;
+                vh = *reinterpret_cast<const uint4*>(p);
+                vl = *reinterpret_cast<const uint4*>(p + 1024);
+            }
+            s_x[(f * 2 + 0) * 64 + lane] = vh;
+            s_x[(f * 2 + 1) * 64 + lane] = vl;
+            if (n < BW) {
+                // channels kb * 32 + kq * 8 + 0..7 = cout tile kb * 2 + (kq >> 1), quads (kq & 1) * 2 and + 1 of it
+                const half8 hh = __builtin_bit_cast(half8, vh), hl = __builtin_bit_cast(half8, vl);
+                float4* r4 = reinterpret_cast<float4*>(res) + ((row * NT + kb * 2 + (kq >> 1)) * 4 + (kq & 1) * 2) * BW + n;
+                r4[0] = make_float4(static_cast<float>(hh[0]) + static_cast<float>(hl[0]), static_cast<float>(hh[1]) + static_cast<float>(hl[1]),
+                                    static_cast<float>(hh[2]) + static_cast<float>(hl[2]), static_cast<float>(hh[3]) + static_cast<float>(hl[3]));
+                r4[BW] = make_float4(static_cast<float>(hh[4]) + static_cast<float>(hl[4]), static_cast<float>(hh[5]) + static_cast<float>(hl[5]),
+                                     static_cast<float>(hh[6]) + static_cast<float>(hl[6]), static_cast<float>(hh[7]) + static_cast<float>(hl[7]));
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < a.nlayers; ++l) {
+            const TrunkHLayer& L = a.layers[l];
+            const bool second = (l & 1) == 0;          // second conv of a ResBlock: + x
+            const bool last = l + 1 == a.nlayers;
+            const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
+            const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
+            const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
+            f32x4 acc[BW];
+#pragma unroll
+            for (int y = 0; y < BW; ++y) acc[y] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // slab = (32-channel block kb, tap row ky): 3 taps x {high, low} weight fragments, streamed from L2 one slab ahead
+            // into the other register set while this slab's sweep multiplies
+            half8 wA[2][3], wB[2][3];
+            auto load_w = [&](int slab, half8 (&W)[2][3]) {
+                const int kb = (slab / 3) % NCI, ky = slab % 3;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ub = (((ky * 3 + kx) * NCI + kb) * NT + tile) * 1024;
+                    W[0][kx] = buf_ld_h8(rs_wh, lane16, ub);
+                    W[1][kx] = buf_ld_h8(rs_wl, lane16, ub);
+                }
+            };
+            load_w(0, wA);
+#pragma unroll 1
+            for (int kb2 = 0; kb2 < NCI; kb2 += 2) {
+#pragma unroll
+                for (int s6 = 0; s6 < 6; ++s6) {           // two blocks x three tap rows: the buffer parity returns to wA
+                    const int kb = kb2 + s6 / 3, ky = s6 % 3;
+                    half8 (&w)[2][3] = (s6 & 1) ? wB : wA;
+                    half8 (&wn)[2][3] = (s6 & 1) ? wA : wB;
+                    load_w(kb2 * 3 + s6 + 1, wn);          // (the last slab of a layer re-requests slab 0: harmless, keeps the loop uniform)
+                    // input row r feeds output row y = r + 1 - ky; two output rows at a time so that consecutive MFMAs
+                    // accumulate into different registers
+                    constexpr int NP = (BW + 1) / 2;
+#pragma unroll
+                    for (int yp = 0; yp < NP; ++yp) {
+                        half8 xh[2][3], xl[2][3];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int y = 2 * yp + j, r = y + ky - 1;
+                            if (y >= BW || r < 0 || r >= BW) continue;   // (uniform: rows off the board are skipped)
+                            xh[j][1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 0) * 64 + lane]);
+                            xl[j][1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 1) * 64 + lane]);
+                            // tap column kx reads input cell (output cell + kx - 1): kx = 0 from the lane below, kx = 2 from the lane above
+                            xh[j][0] = dpp_shift_h8<kDppRowShr1>(xh[j][1]);
+                            xl[j][0] = dpp_shift_h8<kDppRowShr1>(xl[j][1]);
+                            xh[j][2] = dpp_shift_h8<kDppRowShl1>(xh[j][1]);
+                            xl[j][2] = dpp_shift_h8<kDppRowShl1>(xl[j][1]);
+                        }
+                        // products xh*wh, xh*wl, xl*wh
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr) {
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    const int y = 2 * yp + j, r = y + ky - 1;
+                                    if (y >= BW || r < 0 || r >= BW) continue;
+                                    acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[pr == 1 ? 1 : 0][kx], pr == 2 ? xl[j][kx] : xh[j][kx], acc[y], 0, 0, 0);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads of the sweep from being hoisted to its top)
+                    }
+                }
+            }
+            // ---- layer boundary: every wave has read the input; the output replaces it
+            __syncthreads();
+            constexpr int EB = 5;   // output rows per batch of the epilogue: the batch's residual loads are in flight together
+#pragma unroll
+            for (int y0 = 0; y0 < BW; y0 += EB) {
+                f32x4 rx[EB];
+                if (second) {   // the block's input, parked in the scratch when it was produced
+#pragma unroll
+                    for (int k = 0; k < EB; ++k) {
+                        const int y = y0 + k < BW ? y0 + k : BW - 1;
+                        const float4 t = reinterpret_cast<const float4*>(res)[((y * NT + tile) * 4 + kq) * BW + (n < BW ? n : BW - 1)];
+                        rx[k] = f32x4{t.x, t.y, t.z, t.w};
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < EB; ++k) {
+                    const int y = y0 + k;
+                    if (y >= BW) continue;
+                    float f[4] = {fmaf(acc[y][0], sc.x, sh.x), fmaf(acc[y][1], sc.y, sh.y), fmaf(acc[y][2], sc.z, sh.z), fmaf(acc[y][3], sc.w, sh.w)};
+                    if (second) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) f[c] += rx[k][c];
+                    }
+                    half4 hh, hl;
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        peak = fmaxf(peak, n < BW ? f[c] : 0.f);
+                        v[c] = n < BW ? fminf(fmaxf(f[c], 0.f), 65504.f) : 0.f;   // ReLU, fp16-range clamp (reported), zero pad cell
+                        hh[c] = static_cast<_Float16>(v[c]);
+                        hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
+                    }
+                    char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
+                    *reinterpret_cast<half4*>(frag + out_off) = hh;
+                    *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
+                    if (second && !last && n < BW)   // the next block's input
+                        reinterpret_cast<float4*>(res)[((y * NT + tile) * 4 + kq) * BW + n] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the trunk's output back into the group layout (the heads read it there)
+        char* gout = reinterpret_cast<char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
+#pragma unroll 1
+        for (int f = tile; f < BW * NCI; f += NT) {
+            const int row = f / NCI, kb = f % NCI;
+            if (n < BW) {
+                char* p = gout + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;
+                *reinterpret_cast<uint4*>(p) = s_x[(f * 2 + 0) * 64 + lane];
+                *reinterpret_cast<uint4*>(p + 1024) = s_x[(f * 2 + 1) * 64 + lane];
+            }
+        }
+    }
+    if (peak > 65504.f) atomicOr(a.layers[1].ovf, 1);
+}
+
+}  // namespace ao

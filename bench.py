@@ -681,7 +681,7 @@ def main():
         except Exception as e:
             traffic, traffic_why = None, "profile unreadable: %r" % (e,)
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
-        split16 = kname.startswith("k_trunk16h") or kname.startswith("k_layer16h")
+        split16 = kname.startswith(("k_trunk16h", "k_layer16h", "k_row16hk", "k_boardh", "k_conv_cells_h"))
         peak = PEAK_F16_MFMA_TFLOPS if split16 else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "self-play move-decisions/sec (%dx%d, %d sims/move)" % (B, B, S),

@@ -652,3 +652,59 @@ def test_fused_per_game_step_equals_separate_launches(B, G, S, nb, C, monkeypatc
     e1.close()
     e2.close()
     net.close()
+
+
+@pytest.mark.parametrize("nb,B,batch", [(2, 15, 130), (10, 15, 300), (3, 11, 129), (2, 13, 200), (1, 10, 128)])
+def test_board_resident_trunk_wide_boards_vs_torch_and_per_layer(nb, B, batch):
+    """k_boardh<B> (round 5, net_board_h16.hpp): boards wider than 9, from 128 boards on -- a workgroup carries ONE board through
+    all trunk convs, activations resident in LDS, cells as the MFMA N dimension, column shifts as DPP row shifts. Against the
+    torch fp32 module (model.py:76-104) within the 1e-4 of BASELINE.json's north star, against the per-layer kernels
+    (AO_BOARDK=0: same split-fp16 arithmetic, another summation order) within 2e-5, and with a batch that is not a multiple of
+    16 or of the workgroup count (boards loop, partial last group). The dominant kernel is named by the library's own planning."""
+    import os
+    import torch
+    from alpha_omok_amd.engine import plan_kernel
+    from alpha_omok_amd.pvnet import PVNet
+    assert plan_kernel(nb, 5, 128, B, batch, in_kind=1)[0].startswith("k_boardh<%d>" % B)
+    assert plan_kernel(nb, 5, 128, B, 127, in_kind=1)[0].startswith("k_layer16h<%d>" % B)
+    assert plan_kernel(nb, 5, 128, B, batch, in_kind=1, trunk_mode=6)[0].startswith("k_layer16h<%d>" % B)   # one arithmetic for every batch size
+    torch.manual_seed(nb * 100 + B)
+    ref = PVNet(nb, 5, 128, B)       # PyTorch default init (the deterministic generator saturates a 10-block stack)
+    with torch.no_grad():
+        for m in ref.modules():      # non-trivial BatchNorm statistics
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    ref.eval()
+    rs = np.random.RandomState(batch)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    x[:, 4] = (rs.rand(batch, 1, 1) < 0.5).astype(np.float32)
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x))
+    net = ref.to_native(0)
+    p, v = net(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert net.dominant_kernel(batch)[0].startswith("k_boardh<%d>" % B)
+    assert net.status() == 0
+    os.environ["AO_BOARDK"] = "0"
+    try:
+        net_l = ref.to_native(0)
+    finally:
+        del os.environ["AO_BOARDK"]
+    assert net_l.dominant_kernel(batch)[0].startswith("k_layer16h<%d>" % B)
+    pl, vl = net_l(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    dp = np.abs(p.cpu().numpy() - rp.numpy()).max()
+    dv = np.abs(v.cpu().numpy() - rv.numpy()).max()
+    dpl = np.abs(p.cpu().numpy() - pl.cpu().numpy()).max()
+    dvl = np.abs(v.cpu().numpy() - vl.cpu().numpy()).max()
+    assert dp < TOL and dv < TOL, (dp, dv)
+    assert dpl < 2e-5 and dvl < 2e-5, (dpl, dvl)
+    # a second forward on the same buffers gives the same bits (the kernel works in place on the conv1 output)
+    p2, v2 = net(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(p, p2) and torch.equal(v, v2)
+    net.close()
+    net_l.close()
