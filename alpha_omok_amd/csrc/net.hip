@@ -615,7 +615,6 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             if (layer(0)) return 1;
             BoardHArgs a;
             a.act = reinterpret_cast<uint4*>(n->act_x);
-            a.res = n->act_t;
             a.nlayers = 1 + 2 * n->nb;
             a.nboards = boards;
             a.live = live; a.row_cap = row_cap;

@@ -18,19 +18,27 @@
 //     fragments in registers (streamed from L2 one slab ahead: every workgroup of the chip reads the same 590 KB per layer) and
 //     sweeps the board's rows -- 2 LDS reads, 4 DPP shifts and 9 MFMAs per (row, slab), no barrier inside a layer: the waves drift;
 //   * layer boundary = barrier (everyone has read the input) -> epilogue (BatchNorm, residual, ReLU, split, 8-byte LDS writes in
-//     place) -> barrier. The ResBlock input is parked as fp32 in a per-board scratch in global memory (L2-hot, 115 KB) when it is
-//     produced and read back in the epilogue of the block's second conv;
+//     place) -> barrier. The ResBlock input of a wave's own cout tile stays in its registers (60) across the block's two convs;
 //   * conv1 and the heads stay where they are (k_layer16h<BW, ..., KIND 1 / 2>, k_head_conv / k_head_fc): the kernel reads and
 //     writes the 16-board-group layout of the per-layer path, so `ao_net_forward` changes ONE thing -- 2 x n_block launches become one.
 // Same arithmetic family as the other split-fp16 kernels (3 products per multiply-add, fp32 accumulate, weights pre-scaled by a
 // power of two per layer); the summation order over taps / blocks differs, so results agree to fp32 rounding, not bit for bit.
 #pragma once
 
+// Timing knock-outs (-DAO_BKO=n, WRONG RESULTS, experiment builds only: AO_BUILD_TAG): 1 no DPP shifts (every tap column reads the
+// unshifted fragment), 2 the LDS fragments are read once per slab, 3 no epilogue (no LDS writes, no residual traffic), 4 weights of
+// slab 0 only, 5 no board load / write-back.
+#ifndef AO_BKO
+#define AO_BKO 0
+#endif
+#if AO_BKO != 0 && !defined(AO_WRONG_RESULTS_OK)
+#error "AO_BKO builds compute wrong results on purpose: timing only, build them with -DAO_WRONG_RESULTS_OK"
+#endif
+
 namespace ao {
 
 struct BoardHArgs {
     uint4* act;          // [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B: in = conv1's output, out = the trunk's output
-    float* res;          // [board][BW * BW * 128] fp32 scratch: the ResBlock input in D-operand order (see below)
     int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0] is not used here)
     int nboards;
     const unsigned* live;   // live rows of this simulation's batch (net_common.hpp) or null
@@ -67,14 +75,21 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
     // the lane's 8-byte slot inside output fragment (row, tile >> 1, half): cout quad q = kq -> k-octet (tile & 1) * 2 + (kq >> 1)
     const int out_off = (((tile & 1) * 2 + (kq >> 1)) * 16 + n) * 16 + (kq & 1) * 8;
     float peak = 0.f;
-    for (unsigned board = blockIdx.x; board < nlive; board += gridDim.x) {
-        const unsigned grp = board >> 4, bslot = board & 15u;
+    // Which board a workgroup carries: the 16 boards of a GROUP share every 128-byte line of the group layout (a board's share of a
+    // line is 16 bytes), so they go to 16 workgroups of ONE XCD at the same time -- workgroups are dealt round robin over the 8 XCDs:
+    // virtual index v = round * gridDim + blockIdx -> XCD x = v % 8, position j = v / 8: group (j / 16) * 8 + x, slot j % 16. A line
+    // then crosses the fabric once and is hit 15 times in that XCD's L2 (dealt board by board it was fetched by all 8 XCDs).
+    const unsigned nbv = (static_cast<unsigned>(a.nboards) + 127u) & ~127u;   // (whole rounds of 8 groups; boards beyond the batch are skipped)
+    for (unsigned v = blockIdx.x; v < nbv; v += gridDim.x) {
+        const unsigned x8 = v & 7u, j = v >> 3;
+        const unsigned grp = (j >> 4) * 8u + x8, bslot = j & 15u;
+        const unsigned board = grp * 16u + bslot;
+        if (board >= nlive) continue;   // (uniform for the workgroup)
         const char* gact = reinterpret_cast<const char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
-        float* res = a.res + static_cast<size_t>(board) * A * 128;
         // ---- the board's activations (conv1's output) into LDS; the block input x also goes to the scratch as fp32
         __syncthreads();   // (the previous board's write-back has read the buffer)
 #pragma unroll 1
-        for (int f = tile; f < BW * NCI; f += NT) {            // (row, block): both halves
+        for (int f = tile; f < (AO_BKO == 5 ? 0 : BW * NCI); f += NT) {            // (row, block): both halves
             const int row = f / NCI, kb = f % NCI;
             uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
             if (n < BW) {
@@ -84,14 +99,18 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
             }
             s_x[(f * 2 + 0) * 64 + lane] = vh;
             s_x[(f * 2 + 1) * 64 + lane] = vl;
-            if (n < BW) {
-                // channels kb * 32 + kq * 8 + 0..7 = cout tile kb * 2 + (kq >> 1), quads (kq & 1) * 2 and + 1 of it
-                const half8 hh = __builtin_bit_cast(half8, vh), hl = __builtin_bit_cast(half8, vl);
-                float4* r4 = reinterpret_cast<float4*>(res) + ((row * NT + kb * 2 + (kq >> 1)) * 4 + (kq & 1) * 2) * BW + n;
-                r4[0] = make_float4(static_cast<float>(hh[0]) + static_cast<float>(hl[0]), static_cast<float>(hh[1]) + static_cast<float>(hl[1]),
-                                    static_cast<float>(hh[2]) + static_cast<float>(hl[2]), static_cast<float>(hh[3]) + static_cast<float>(hl[3]));
-                r4[BW] = make_float4(static_cast<float>(hh[4]) + static_cast<float>(hl[4]), static_cast<float>(hh[5]) + static_cast<float>(hl[5]),
-                                     static_cast<float>(hh[6]) + static_cast<float>(hl[6]), static_cast<float>(hh[7]) + static_cast<float>(hl[7]));
+        }
+        // the ResBlock input of THIS wave's cout tile stays in registers across the block's two convs (60 registers; parked in a
+        // global scratch it cost a round trip per epilogue batch and 2.4 GB of L2 traffic per launch): x = xh + xl of conv1's output
+        f32x4 xres[BW];
+#pragma unroll
+        for (int y = 0; y < BW; ++y) {
+            xres[y] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < BW && AO_BKO != 5) {
+                const char* p = gact + (static_cast<size_t>(y * BW + n) * NCI + (tile >> 1)) * 2048u + (((tile & 1) * 2 + (kq >> 1)) * 16 + bslot) * 16 + (kq & 1) * 8;
+                const half4 hh = *reinterpret_cast<const half4*>(p), hl = *reinterpret_cast<const half4*>(p + 1024);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xres[y][c] = static_cast<float>(hh[c]) + static_cast<float>(hl[c]);
             }
         }
         __syncthreads();
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                     const int kb = kb2 + s6 / 3, ky = s6 % 3;
                     half8 (&w)[2][3] = (s6 & 1) ? wB : wA;
                     half8 (&wn)[2][3] = (s6 & 1) ? wA : wB;
-                    load_w(kb2 * 3 + s6 + 1, wn);          // (the last slab of a layer re-requests slab 0: harmless, keeps the loop uniform)
+                    if (AO_BKO != 4) load_w(kb2 * 3 + s6 + 1, wn);          // (the last slab of a layer re-requests slab 0: harmless, keeps the loop uniform)
                     // input row r feeds output row y = r + 1 - ky; two output rows at a time so that consecutive MFMAs
                     // accumulate into different registers
                     constexpr int NP = (BW + 1) / 2;
@@ -137,8 +156,14 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                         for (int j = 0; j < 2; ++j) {
                             const int y = 2 * yp + j, r = y + ky - 1;
                             if (y >= BW || r < 0 || r >= BW) continue;   // (uniform: rows off the board are skipped)
-                            xh[j][1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 0) * 64 + lane]);
-                            xl[j][1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 1) * 64 + lane]);
+                            const int rr = AO_BKO == 2 ? 0 : r;
+                            xh[j][1] = __builtin_bit_cast(half8, s_x[((rr * NCI + kb) * 2 + 0) * 64 + lane]);
+                            xl[j][1] = __builtin_bit_cast(half8, s_x[((rr * NCI + kb) * 2 + 1) * 64 + lane]);
+                            if (AO_BKO == 1) {
+                                xh[j][0] = xh[j][2] = xh[j][1];
+                                xl[j][0] = xl[j][2] = xl[j][1];
+                                continue;
+                            }
                             // tap column kx reads input cell (output cell + kx - 1): kx = 0 from the lane below, kx = 2 from the lane above
                             xh[j][0] = dpp_shift_h8<kDppRowShr1>(xh[j][1]);
                             xl[j][0] = dpp_shift_h8<kDppRowShr1>(xl[j][1]);
@@ -158,55 +183,45 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                                 }
                             }
                         }
-                        __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads of the sweep from being hoisted to its top)
+                        if (AO_BKO != 2) __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads of the sweep from being hoisted to its top)
                     }
                 }
             }
             // ---- layer boundary: every wave has read the input; the output replaces it
             __syncthreads();
-            constexpr int EB = 5;   // output rows per batch of the epilogue: the batch's residual loads are in flight together
+            if (AO_BKO == 3) {
 #pragma unroll
-            for (int y0 = 0; y0 < BW; y0 += EB) {
-                f32x4 rx[EB];
-                if (second) {   // the block's input, parked in the scratch when it was produced
+                for (int y = 0; y < BW; ++y) asm volatile("" ::"v"(acc[y]));
+                __syncthreads();
+                continue;
+            }
 #pragma unroll
-                    for (int k = 0; k < EB; ++k) {
-                        const int y = y0 + k < BW ? y0 + k : BW - 1;
-                        const float4 t = reinterpret_cast<const float4*>(res)[((y * NT + tile) * 4 + kq) * BW + (n < BW ? n : BW - 1)];
-                        rx[k] = f32x4{t.x, t.y, t.z, t.w};
-                    }
+            for (int y = 0; y < BW; ++y) {
+                float f[4] = {fmaf(acc[y][0], sc.x, sh.x), fmaf(acc[y][1], sc.y, sh.y), fmaf(acc[y][2], sc.z, sh.z), fmaf(acc[y][3], sc.w, sh.w)};
+                if (second) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) f[c] += xres[y][c];
                 }
+                half4 hh, hl;
+                float v[4];
 #pragma unroll
-                for (int k = 0; k < EB; ++k) {
-                    const int y = y0 + k;
-                    if (y >= BW) continue;
-                    float f[4] = {fmaf(acc[y][0], sc.x, sh.x), fmaf(acc[y][1], sc.y, sh.y), fmaf(acc[y][2], sc.z, sh.z), fmaf(acc[y][3], sc.w, sh.w)};
-                    if (second) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) f[c] += rx[k][c];
-                    }
-                    half4 hh, hl;
-                    float v[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        peak = fmaxf(peak, n < BW ? f[c] : 0.f);
-                        v[c] = n < BW ? fminf(fmaxf(f[c], 0.f), 65504.f) : 0.f;   // ReLU, fp16-range clamp (reported), zero pad cell
-                        hh[c] = static_cast<_Float16>(v[c]);
-                        hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
-                    }
-                    char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
-                    *reinterpret_cast<half4*>(frag + out_off) = hh;
-                    *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
-                    if (second && !last && n < BW)   // the next block's input
-                        reinterpret_cast<float4*>(res)[((y * NT + tile) * 4 + kq) * BW + n] = make_float4(v[0], v[1], v[2], v[3]);
+                for (int c = 0; c < 4; ++c) {
+                    peak = fmaxf(peak, n < BW ? f[c] : 0.f);
+                    v[c] = n < BW ? fminf(fmaxf(f[c], 0.f), 65504.f) : 0.f;   // ReLU, fp16-range clamp (reported), zero pad cell
+                    hh[c] = static_cast<_Float16>(v[c]);
+                    hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
                 }
+                char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
+                *reinterpret_cast<half4*>(frag + out_off) = hh;
+                *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
+                if (second) xres[y] = f32x4{v[0], v[1], v[2], v[3]};   // the next block's input
             }
             __syncthreads();
         }
         // ---- the trunk's output back into the group layout (the heads read it there)
         char* gout = reinterpret_cast<char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
 #pragma unroll 1
-        for (int f = tile; f < BW * NCI; f += NT) {
+        for (int f = tile; f < (AO_BKO == 5 ? 0 : BW * NCI); f += NT) {
             const int row = f / NCI, kb = f % NCI;
             if (n < BW) {
                 char* p = gout + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;

@@ -1,7 +1,7 @@
 # round 5: k_boardh<15> (one board resident in LDS through all trunk convs, cells as MFMA N) against k_layer16h<15> (AO_BOARDK=0): numerics, then the
 # configs[4] per-GPU shape (15x15, 10 blocks, 800 sims, 1024 games), same box, alternating
 python -m pytest tests/test_gpu_net.py -x -q -k "board_resident" 2>&1 | tail -8
-for rep in 1 2; do
+for rep in 1; do
 for bk in 128 0; do
 AO_BOARDK=$bk python bench.py --board 15 --games 1024 --sims 800 --blocks 10 --steps 2 --warmup 1 --no-cpu-baseline --no-single-game --no-fp32-compare --no-ten-block --no-tictactoe --no-trained-net > gpurun_out/r5i_bench15_$bk.json 2>gpurun_out/r5i_err_$bk.txt
 python -c "
