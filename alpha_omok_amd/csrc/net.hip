@@ -611,10 +611,16 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             return 0;
         };
         if (board_resident(n, boards)) {
-            // conv1 as before, then ALL trunk convs in one launch: a workgroup per board (net_board_h16.hpp)
-            if (layer(0)) return 1;
+            // ONE launch: a workgroup per board carries it from the bit planes through conv1, all trunk convs and both heads
+            // (net_board_h16.hpp). Float planes (ao_net_forward): conv1 as k_layer16h first, its output gathered by the kernel.
+            const bool bits = in_kind == 2 && n->step_w1h != nullptr;
+            if (!bits && layer(0)) return 1;
             BoardHArgs a;
-            a.act = reinterpret_cast<uint4*>(n->act_x);
+            a.act = reinterpret_cast<const uint4*>(n->act_x);
+            a.planes = reinterpret_cast<const uint8_t*>(in_il);
+            a.w1h = n->step_w1h;
+            a.w1l = n->step_w1l;
+            a.out = reinterpret_cast<float4*>(n->act_t);
             a.nlayers = 1 + 2 * n->nb;
             a.nboards = boards;
             a.live = live; a.row_cap = row_cap;
@@ -632,17 +638,30 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
     case W: {                                                                                                          \
         constexpr size_t lds_ = static_cast<size_t>(W) * 8 * 1024;                                                     \
         if (!n->attr_b[W]) {                                                                                           \
-            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boardh<W>),                                \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boardh<W, 1>),                             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
+            NET_HIP(n, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_boardh<W, 2>),                             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_)));       \
             n->attr_b[W] = true;                                                                                       \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_boardh<W>), grid, block, lds_, s, a);                                                    \
+        if (bits) hipLaunchKernelGGL((k_boardh<W, 2>), grid, block, lds_, s, a);                                       \
+        else hipLaunchKernelGGL((k_boardh<W, 1>), grid, block, lds_, s, a);                                            \
     } break;
                 AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
                 default: return n->fail("k_boardh: board outside 10 .. 15");
             }
             if (n->timing) timer_end(n, idx, s);
+            NET_HIP(n, hipGetLastError());
+            // the heads on the kernel's fp32 NHWC output: the batched head kernels with "groups" of one board
+            const int nchunk1 = (n->A + 255) / 256;
+            hipLaunchKernelGGL(k_head_conv<false>, dim3(boards * nchunk1), dim3(256), 3 * n->planes * sizeof(float), s,
+                               reinterpret_cast<const float4*>(n->act_t), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf, n->A, n->CQ, 1);
+            const size_t lds1 = (static_cast<size_t>(4) * n->A + n->planes + 8) * sizeof(float);
+            hipLaunchKernelGGL(k_head_fc, dim3(boards), dim3(256), lds1, s, n->hbuf, n->wp_t, n->bp, n->w1_t, n->b1, n->w2, n->b2, policy, value,
+                               n->A, n->planes);
+            NET_HIP(n, hipGetLastError());
+            return 0;
         } else {
             for (int l = 0; l <= 2 * n->nb; ++l)
                 if (layer(l)) return 1;
@@ -1204,9 +1223,10 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
              ", waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
     } else if (group == 16 && mode == 5 && board_resident(n, boards)) {
-        nm = "k_boardh<" + bw + "> (" + std::to_string(2 * n->nb) + " 3x3 convs in one launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
+        nm = "k_boardh<" + bw + (in_kind == 2 ? ", 2" : ", 1") + "> (" + (in_kind == 2 ? "conv1 + " : "") + std::to_string(2 * n->nb) +
+             " 3x3 convs in one launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
              "a workgroup = one board resident in LDS through all layers, the row's cells as the MFMA N dimension, column shifts as DPP row shifts)";
-        f = 2.0 * n->nb * 2.0 * n->A * 9.0 * n->planes * n->planes * boards;
+        f = 2.0 * n->nb * 2.0 * n->A * 9.0 * n->planes * n->planes * boards + (in_kind == 2 ? 2.0 * n->A * 9.0 * n->C * n->planes * boards : 0.0);
     } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (boards + 15) / 16 >= 192))) {
         nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
              "16-board groups x row chunks x column tiles)";

@@ -19,8 +19,12 @@
 //     sweeps the board's rows -- 2 LDS reads, 4 DPP shifts and 9 MFMAs per (row, slab), no barrier inside a layer: the waves drift;
 //   * layer boundary = barrier (everyone has read the input) -> epilogue (BatchNorm, residual, ReLU, split, 8-byte LDS writes in
 //     place) -> barrier. The ResBlock input of a wave's own cout tile stays in its registers (60) across the block's two convs;
-//   * conv1 and the heads stay where they are (k_layer16h<BW, ..., KIND 1 / 2>, k_head_conv / k_head_fc): the kernel reads and
-//     writes the 16-board-group layout of the per-layer path, so `ao_net_forward` changes ONE thing -- 2 x n_block launches become one.
+//   * conv1 runs in the same launch on the engine's bit planes (ao_search; 90 MFMAs per wave, K = tap * 8 + plane) -- or, for
+//     ao_net_forward's arbitrary float planes, as k_layer16h<BW, ..., KIND 1> before it, its output gathered from the group layout
+//     (a group's 16 boards go to 16 workgroups of one XCD: they share every line). The output is written as fp32 NHWC, 64-byte
+//     segments, for the batched head kernels (k_head_conv / k_head_fc: 405 KB of policy_fc weights per board want the whole chip,
+//     not one workgroup -- run inside this kernel by heads_board_dev the heads cost 70 us per board, 0.28 ms per launch of 1024
+//     boards against 0.1 ms for the two batched launches): 23 launches become 3.
 // Same arithmetic family as the other split-fp16 kernels (3 products per multiply-add, fp32 accumulate, weights pre-scaled by a
 // power of two per layer); the summation order over taps / blocks differs, so results agree to fp32 rounding, not bit for bit.
 #pragma once
@@ -38,8 +42,12 @@
 namespace ao {
 
 struct BoardHArgs {
-    uint4* act;          // [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B: in = conv1's output, out = the trunk's output
-    int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0] is not used here)
+    const uint4* act;    // IN 1: conv1's output in the group layout [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B (k_layer16h KIND 1)
+    const uint8_t* planes;   // IN 2: the engine's bit planes, [board][kPlaneRow(BW)] bytes, bit q = plane q (tree_device.hpp encode_planes)
+    const uint4* w1h;    // IN 2: conv1 weights as split-fp16 A fragments, K = tap * 8 + plane padded to 96: [k step 3][cout tile 8][lane 64] (StepNet)
+    const uint4* w1l;
+    float4* out;         // [board][cell][32] float4: the trunk's output, fp32 NHWC (k_head_conv<false> with groups of ONE board reads it)
+    int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0]: its BatchNorm scale / shift for IN 2)
     int nboards;
     const unsigned* live;   // live rows of this simulation's batch (net_common.hpp) or null
     unsigned row_cap;
@@ -56,9 +64,12 @@ __device__ __forceinline__ half8 dpp_shift_h8(const half8 v) {
     return __builtin_bit_cast(half8, r);
 }
 
-template <int BW>
+// IN: 2 = conv1 runs here, on the engine's bit planes (ao_search); 1 = conv1 ran as k_layer16h on the fp32 plane batch (ao_net_forward
+// takes any float planes) and its output is gathered from the group layout
+template <int BW, int IN>
 __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
     static_assert(BW >= 10 && BW <= 15, "rows are padded to 16 cells and need at least one zero pad");
+    __shared__ uint8_t s_pl[256];                  // IN 2: the board's plane bytes
     constexpr int A = BW * BW;
     constexpr int NCI = 4, NT = 8;                 // 128 channels: four 32-channel blocks, eight 16-channel cout tiles
     constexpr int NFR = BW * NCI * 2;              // 1 KB fragments of the board
@@ -86,31 +97,81 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
         const unsigned board = grp * 16u + bslot;
         if (board >= nlive) continue;   // (uniform for the workgroup)
         const char* gact = reinterpret_cast<const char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
-        // ---- the board's activations (conv1's output) into LDS; the block input x also goes to the scratch as fp32
-        __syncthreads();   // (the previous board's write-back has read the buffer)
-#pragma unroll 1
-        for (int f = tile; f < (AO_BKO == 5 ? 0 : BW * NCI); f += NT) {            // (row, block): both halves
-            const int row = f / NCI, kb = f % NCI;
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-            if (n < BW) {
-                const char* p = gact + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;
-                vh = *reinterpret_cast<const uint4*>(p);
-                vl = *reinterpret_cast<const uint4*>(p + 1024);
-            }
-            s_x[(f * 2 + 0) * 64 + lane] = vh;
-            s_x[(f * 2 + 1) * 64 + lane] = vl;
-        }
         // the ResBlock input of THIS wave's cout tile stays in registers across the block's two convs (60 registers; parked in a
-        // global scratch it cost a round trip per epilogue batch and 2.4 GB of L2 traffic per launch): x = xh + xl of conv1's output
+        // global scratch it cost a round trip per epilogue batch and 2.4 GB of L2 traffic per launch)
         f32x4 xres[BW];
+        __syncthreads();   // (the previous board's last layer has read the buffer)
+        if (IN == 2) {
+            // ---- conv1 (model.py:86-89) on the board's bit planes: K = tap * 8 + plane, three k steps of 32; a lane's B operand for
+            // step ks is the plane byte of cell (row + tap row - 1, cell + tap column - 1), tap = 4 ks + k-octet, expanded to eight
+            // halves 0 / 1 (exact: no low half, two products). 90 MFMAs per wave.
+            if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(s_pl)[threadIdx.x] =
+                reinterpret_cast<const uint32_t*>(a.planes + static_cast<size_t>(board) * kPlaneRow(BW))[threadIdx.x < kPlaneRow(BW) / 4 ? threadIdx.x : 0];
+            half8 ah[3], al[3];
 #pragma unroll
-        for (int y = 0; y < BW; ++y) {
-            xres[y] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < BW && AO_BKO != 5) {
-                const char* p = gact + (static_cast<size_t>(y * BW + n) * NCI + (tile >> 1)) * 2048u + (((tile & 1) * 2 + (kq >> 1)) * 16 + bslot) * 16 + (kq & 1) * 8;
-                const half4 hh = *reinterpret_cast<const half4*>(p), hl = *reinterpret_cast<const half4*>(p + 1024);
+            for (int ks = 0; ks < 3; ++ks) {
+                ah[ks] = __builtin_bit_cast(half8, a.w1h[(ks * NT + tile) * 64 + lane]);
+                al[ks] = __builtin_bit_cast(half8, a.w1l[(ks * NT + tile) * 64 + lane]);
+            }
+            const float4 sc1 = a.layers[0].sc[tile * 4 + kq], sh1 = a.layers[0].sh[tile * 4 + kq];
+            __syncthreads();
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xres[y][c] = static_cast<float>(hh[c]) + static_cast<float>(hl[c]);
+            for (int y = 0; y < BW; ++y) {
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int tap = 4 * ks + kq;
+                    const int r = y + tap / 3 - 1, x = n + tap % 3 - 1;
+                    unsigned bq = 0;
+                    if (tap < 9 && r >= 0 && r < BW && x >= 0 && x < BW) bq = s_pl[r * BW + x];
+                    uint4 v;
+                    v.x = ((bq & 1u) ? 0x3C00u : 0u) | ((bq & 2u) ? 0x3C000000u : 0u);
+                    v.y = ((bq & 4u) ? 0x3C00u : 0u) | ((bq & 8u) ? 0x3C000000u : 0u);
+                    v.z = ((bq & 16u) ? 0x3C00u : 0u) | ((bq & 32u) ? 0x3C000000u : 0u);
+                    v.w = ((bq & 64u) ? 0x3C00u : 0u) | ((bq & 128u) ? 0x3C000000u : 0u);
+                    const half8 xb = __builtin_bit_cast(half8, v);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xb, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], xb, c1, 0, 0, 0);
+                }
+                const float f[4] = {fmaf(c0[0] + c1[0], sc1.x, sh1.x), fmaf(c0[1] + c1[1], sc1.y, sh1.y), fmaf(c0[2] + c1[2], sc1.z, sh1.z),
+                                    fmaf(c0[3] + c1[3], sc1.w, sh1.w)};
+                half4 hh, hl;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    peak = fmaxf(peak, n < BW ? f[c] : 0.f);
+                    v[c] = n < BW ? fminf(fmaxf(f[c], 0.f), 65504.f) : 0.f;
+                    hh[c] = static_cast<_Float16>(v[c]);
+                    hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
+                }
+                char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
+                *reinterpret_cast<half4*>(frag + out_off) = hh;
+                *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
+                xres[y] = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        } else {
+            // ---- the board's activations (conv1's output) out of the group layout into LDS
+#pragma unroll 1
+            for (int f = tile; f < (AO_BKO == 5 ? 0 : BW * NCI); f += NT) {            // (row, block): both halves
+                const int row = f / NCI, kb = f % NCI;
+                uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+                if (n < BW) {
+                    const char* p = gact + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;
+                    vh = *reinterpret_cast<const uint4*>(p);
+                    vl = *reinterpret_cast<const uint4*>(p + 1024);
+                }
+                s_x[(f * 2 + 0) * 64 + lane] = vh;
+                s_x[(f * 2 + 1) * 64 + lane] = vl;
+            }
+#pragma unroll
+            for (int y = 0; y < BW; ++y) {   // x = xh + xl of conv1's output, this wave's cout tile in D-operand order
+                xres[y] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < BW && AO_BKO != 5) {
+                    const char* p = gact + (static_cast<size_t>(y * BW + n) * NCI + (tile >> 1)) * 2048u + (((tile & 1) * 2 + (kq >> 1)) * 16 + bslot) * 16 + (kq & 1) * 8;
+                    const half4 hh = *reinterpret_cast<const half4*>(p), hl = *reinterpret_cast<const half4*>(p + 1024);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xres[y][c] = static_cast<float>(hh[c]) + static_cast<float>(hl[c]);
+                }
             }
         }
         __syncthreads();
@@ -211,23 +272,16 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                     hh[c] = static_cast<_Float16>(v[c]);
                     hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
                 }
+                if (last) {   // the trunk's output: fp32 NHWC in global memory (the heads below read it from L2)
+                    if (n < BW) a.out[(static_cast<size_t>(board) * A + y * BW + n) * 32 + tile * 4 + kq] = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
                 char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
                 *reinterpret_cast<half4*>(frag + out_off) = hh;
                 *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
                 if (second) xres[y] = f32x4{v[0], v[1], v[2], v[3]};   // the next block's input
             }
             __syncthreads();
-        }
-        // ---- the trunk's output back into the group layout (the heads read it there)
-        char* gout = reinterpret_cast<char*>(a.act) + static_cast<size_t>(grp) * A * NCI * 2048u;
-#pragma unroll 1
-        for (int f = tile; f < (AO_BKO == 5 ? 0 : BW * NCI); f += NT) {
-            const int row = f / NCI, kb = f % NCI;
-            if (n < BW) {
-                char* p = gout + (static_cast<size_t>(row * BW + n) * NCI + kb) * 2048u + (kq * 16 + bslot) * 16;
-                *reinterpret_cast<uint4*>(p) = s_x[(f * 2 + 0) * 64 + lane];
-                *reinterpret_cast<uint4*>(p + 1024) = s_x[(f * 2 + 1) * 64 + lane];
-            }
         }
     }
     if (peak > 65504.f) atomicOr(a.layers[1].ovf, 1);

@@ -665,7 +665,7 @@ def test_board_resident_trunk_wide_boards_vs_torch_and_per_layer(nb, B, batch):
     import torch
     from alpha_omok_amd.engine import plan_kernel
     from alpha_omok_amd.pvnet import PVNet
-    assert plan_kernel(nb, 5, 128, B, batch, in_kind=1)[0].startswith("k_boardh<%d>" % B)
+    assert plan_kernel(nb, 5, 128, B, batch, in_kind=1)[0].startswith("k_boardh<%d," % B)
     assert plan_kernel(nb, 5, 128, B, 127, in_kind=1)[0].startswith("k_layer16h<%d>" % B)
     assert plan_kernel(nb, 5, 128, B, batch, in_kind=1, trunk_mode=6)[0].startswith("k_layer16h<%d>" % B)   # one arithmetic for every batch size
     torch.manual_seed(nb * 100 + B)
@@ -686,7 +686,7 @@ def test_board_resident_trunk_wide_boards_vs_torch_and_per_layer(nb, B, batch):
     net = ref.to_native(0)
     p, v = net(torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
-    assert net.dominant_kernel(batch)[0].startswith("k_boardh<%d>" % B)
+    assert net.dominant_kernel(batch)[0].startswith("k_boardh<%d," % B)
     assert net.status() == 0
     os.environ["AO_BOARDK"] = "0"
     try:
