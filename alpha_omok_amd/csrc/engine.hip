@@ -293,7 +293,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.row_of_game = nullptr;
     p.live = nullptr;
     p.row_cap = 0;
-    p.ctl = nullptr; p.ctl_cur = 0; p.live_prev = nullptr; p.row_target = 0;
+    p.ctl = nullptr; p.ctl_cur = 0; p.live_prev = nullptr; p.row_target = 0; p.max_levels = 0;
     AO_HIP(e, hipMemsetAsync(e->d_planes_u8, 0, static_cast<size_t>(Gp) * p.u8_row, e->stream));
     p.batch_u8 = nullptr;
     e->il_bytes = static_cast<size_t>(Gp) * A * p.nchq * 4 * sizeof(float);
@@ -756,6 +756,9 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // leaves), measured over the previous move of this engine, less three standard deviations of that binomial; the window moves on
     // by its own length per launch (see select_game). `unfinished` = games that still need simulations.
     const bool oversub = dynamic && cap_rows < rows;
+    static const int level_budget = getenv("AO_DESCENT_BUDGET") ? atoi(getenv("AO_DESCENT_BUDGET")) : 0;   // experiment: levels of a descent per launch
+    p.max_levels = dynamic ? level_budget : 0;
+    const bool catch_up = oversub || p.max_levels > 0;   // games may be short of their simulations after the nominal number of launches
     const int64_t rows_live_before = e->rs_rows_live;
     int64_t sims_wanted = 0;
     for (int g = 0; g < e->G; ++g)
@@ -875,7 +878,7 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         for (int k = 0; k < planned - 8 && rc == 0; ++k) rc = one_sim();   // (a few short: the deficit rounds below find out exactly)
         if (rc) return rc;
     }
-    if (oversub) {
+    if (catch_up) {
         // over-subscribed: leaves that found their simulation's batch full were expanded one launch later, so some games are
         // short of their simulations. The counters say by how much; max(largest deficit, all deficits / rows per launch)
         // is a lower bound of the launches still needed -- run them, look again.
@@ -898,7 +901,8 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
                 const int d = h_target[g] - h_done[g];
                 if (d > 0) { sum += d; mx = std::max(mx, d); }
             }
-            if (mx == 0 || bad || sum == last_sum) break;   // done / a per-game error (reported by ao_end_move) / no progress
+            if (mx == 0 || bad) break;                      // done / a per-game error (reported by ao_end_move)
+            if (sum == last_sum && p.max_levels == 0) break;   // no progress (with a level budget a round may pass without a finished simulation)
             last_sum = sum;
             const int extra = std::max<int64_t>(mx, (sum + cap_rows - 1) / cap_rows);
             for (int k = 0; k < extra && rc == 0; ++k) rc = one_sim();

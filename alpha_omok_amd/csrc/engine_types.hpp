@@ -35,7 +35,9 @@ constexpr int32_t CH_TERMINAL = -2;   // visited child whose position ends the g
 // position are stored -- but every row of the evaluation batch was taken (TreeParams::row_cap); the game asks again in the
 // next launch, before anyone else, and is expanded one launch later. Nothing observable changes: a game's search is strictly
 // sequential either way.
-enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3, LS_WAIT = 4, LS_WAIT_ROOT = 5 };
+// LS_DESCEND: the descent of this simulation used up the launch's level budget (TreeParams::max_levels) and goes on in the next launch
+// from the node it reached (path so far stored; the node itself in the path slot behind it).
+enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3, LS_WAIT = 4, LS_WAIT_ROOT = 5, LS_DESCEND = 6 };
 
 // per-game error bits
 enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
@@ -103,6 +105,10 @@ struct TreeParams {
     // launch was asked for and steers towards row_target (a little below row_cap). ctl: [2][4] words, slot (launch & 1) holds
     // this launch's {sit_n, sit_off, sit as float bits}; null = nobody sits out.
     unsigned* ctl; int ctl_cur; const unsigned* live_prev; unsigned row_target;
+    // A launch of the tree kernel lasts as long as its DEEPEST descent (trained network: ~55 levels against a mean of 14.5). With
+    // max_levels > 0 (rows handed out per simulation only) a descent pauses after that many levels of one launch and resumes in
+    // the next (LS_DESCEND); the game takes no row meanwhile. 0 = no budget.
+    int max_levels;
     unsigned row_cap;     // rows one simulation may hand out (the evaluation batch the trunk is launched for); a game that finds
                           // them taken waits for the next launch (LS_WAIT): more games than rows = over-subscription
     const float* policy;  // [G][A]

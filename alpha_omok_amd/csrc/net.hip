@@ -613,13 +613,11 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
         if (board_resident(n, boards)) {
             // ONE launch: a workgroup per board carries it from the bit planes through conv1, all trunk convs and both heads
             // (net_board_h16.hpp). Float planes (ao_net_forward): conv1 as k_layer16h first, its output gathered by the kernel.
-            const bool bits = in_kind == 2 && n->step_w1h != nullptr;
+            const bool bits = in_kind == 2;
             if (!bits && layer(0)) return 1;
             BoardHArgs a;
             a.act = reinterpret_cast<const uint4*>(n->act_x);
             a.planes = reinterpret_cast<const uint8_t*>(in_il);
-            a.w1h = n->step_w1h;
-            a.w1l = n->step_w1l;
             a.out = reinterpret_cast<float4*>(n->act_t);
             a.nlayers = 1 + 2 * n->nb;
             a.nboards = boards;

@@ -44,8 +44,6 @@ namespace ao {
 struct BoardHArgs {
     const uint4* act;    // IN 1: conv1's output in the group layout [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B (k_layer16h KIND 1)
     const uint8_t* planes;   // IN 2: the engine's bit planes, [board][kPlaneRow(BW)] bytes, bit q = plane q (tree_device.hpp encode_planes)
-    const uint4* w1h;    // IN 2: conv1 weights as split-fp16 A fragments, K = tap * 8 + plane padded to 96: [k step 3][cout tile 8][lane 64] (StepNet)
-    const uint4* w1l;
     float4* out;         // [board][cell][32] float4: the trunk's output, fp32 NHWC (k_head_conv<false> with groups of ONE board reads it)
     int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0]: its BatchNorm scale / shift for IN 2)
     int nboards;
@@ -102,52 +100,65 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
         f32x4 xres[BW];
         __syncthreads();   // (the previous board's last layer has read the buffer)
         if (IN == 2) {
-            // ---- conv1 (model.py:86-89) on the board's bit planes: K = tap * 8 + plane, three k steps of 32; a lane's B operand for
-            // step ks is the plane byte of cell (row + tap row - 1, cell + tap column - 1), tap = 4 ks + k-octet, expanded to eight
-            // halves 0 / 1 (exact: no low half, two products). 90 MFMAs per wave.
+            // ---- conv1 (model.py:86-89) on the board's bit planes: a lane's B operand for a tap is the plane byte of cell (row + tap row - 1,
+            // cell + tap column - 1) expanded to eight halves 0 / 1 (exact: no low half, two products).
             if (threadIdx.x < 64) reinterpret_cast<uint32_t*>(s_pl)[threadIdx.x] =
                 reinterpret_cast<const uint32_t*>(a.planes + static_cast<size_t>(board) * kPlaneRow(BW))[threadIdx.x < kPlaneRow(BW) / 4 ? threadIdx.x : 0];
-            half8 ah[3], al[3];
+            // Same operands in the same order as conv1 of the per-layer path (k_layer16h KIND 2 / KIND 1 on 0 / 1 planes: per output cell
+            // tap rows ascending, tap columns ascending, wh then wl into ONE accumulator), so a position's evaluation has the same bits
+            // whether its planes came as bits (ao_search) or as floats (ao_net_forward, the step-wise protocol): 18 MFMAs per output row,
+            // three rows interleaved.
+            half8 ah[9], al[9];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                ah[ks] = __builtin_bit_cast(half8, a.w1h[(ks * NT + tile) * 64 + lane]);
-                al[ks] = __builtin_bit_cast(half8, a.w1l[(ks * NT + tile) * 64 + lane]);
+            for (int t = 0; t < 9; ++t) {
+                ah[t] = __builtin_bit_cast(half8, a.layers[0].wh[(t * NT + tile) * 64 + lane]);
+                al[t] = __builtin_bit_cast(half8, a.layers[0].wl[(t * NT + tile) * 64 + lane]);
             }
             const float4 sc1 = a.layers[0].sc[tile * 4 + kq], sh1 = a.layers[0].sh[tile * 4 + kq];
             __syncthreads();
 #pragma unroll
-            for (int y = 0; y < BW; ++y) {
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+            for (int y0 = 0; y0 < BW; y0 += 3) {
+                f32x4 c[3];
 #pragma unroll
-                for (int ks = 0; ks < 3; ++ks) {
-                    const int tap = 4 * ks + kq;
-                    const int r = y + tap / 3 - 1, x = n + tap % 3 - 1;
-                    unsigned bq = 0;
-                    if (tap < 9 && r >= 0 && r < BW && x >= 0 && x < BW) bq = s_pl[r * BW + x];
-                    uint4 v;
-                    v.x = ((bq & 1u) ? 0x3C00u : 0u) | ((bq & 2u) ? 0x3C000000u : 0u);
-                    v.y = ((bq & 4u) ? 0x3C00u : 0u) | ((bq & 8u) ? 0x3C000000u : 0u);
-                    v.z = ((bq & 16u) ? 0x3C00u : 0u) | ((bq & 32u) ? 0x3C000000u : 0u);
-                    v.w = ((bq & 64u) ? 0x3C00u : 0u) | ((bq & 128u) ? 0x3C000000u : 0u);
-                    const half8 xb = __builtin_bit_cast(half8, v);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], xb, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], xb, c1, 0, 0, 0);
-                }
-                const float f[4] = {fmaf(c0[0] + c1[0], sc1.x, sh1.x), fmaf(c0[1] + c1[1], sc1.y, sh1.y), fmaf(c0[2] + c1[2], sc1.z, sh1.z),
-                                    fmaf(c0[3] + c1[3], sc1.w, sh1.w)};
-                half4 hh, hl;
-                float v[4];
+                for (int j = 0; j < 3; ++j) c[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    peak = fmaxf(peak, n < BW ? f[c] : 0.f);
-                    v[c] = n < BW ? fminf(fmaxf(f[c], 0.f), 65504.f) : 0.f;
-                    hh[c] = static_cast<_Float16>(v[c]);
-                    hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
+                for (int t = 0; t < 9; ++t) {
+                    half8 xb[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int r = y0 + j + t / 3 - 1, x = n + t % 3 - 1;
+                        unsigned bq = 0;
+                        if (kq == 0 && y0 + j < BW && r >= 0 && r < BW && x >= 0 && x < BW) bq = s_pl[r * BW + x];   // channels 0..7 = the k-octet 0 lanes
+                        uint4 v;
+                        v.x = ((bq & 1u) ? 0x3C00u : 0u) | ((bq & 2u) ? 0x3C000000u : 0u);
+                        v.y = ((bq & 4u) ? 0x3C00u : 0u) | ((bq & 8u) ? 0x3C000000u : 0u);
+                        v.z = ((bq & 16u) ? 0x3C00u : 0u) | ((bq & 32u) ? 0x3C000000u : 0u);
+                        v.w = ((bq & 64u) ? 0x3C00u : 0u) | ((bq & 128u) ? 0x3C000000u : 0u);
+                        xb[j] = __builtin_bit_cast(half8, v);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], xb[j], c[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], xb[j], c[j], 0, 0, 0);
                 }
-                char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
-                *reinterpret_cast<half4*>(frag + out_off) = hh;
-                *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
-                xres[y] = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int y = y0 + j;
+                    if (y >= BW) continue;
+                    const float f[4] = {fmaf(c[j][0], sc1.x, sh1.x), fmaf(c[j][1], sc1.y, sh1.y), fmaf(c[j][2], sc1.z, sh1.z), fmaf(c[j][3], sc1.w, sh1.w)};
+                    half4 hh, hl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        peak = fmaxf(peak, n < BW ? f[k] : 0.f);
+                        const float v = n < BW ? fminf(fmaxf(f[k], 0.f), 65504.f) : 0.f;
+                        hh[k] = static_cast<_Float16>(v);
+                        hl[k] = static_cast<_Float16>(v - static_cast<float>(hh[k]));
+                        xres[y][k] = static_cast<float>(hh[k]) + static_cast<float>(hl[k]);   // (what the gather of IN 1 reconstructs)
+                    }
+                    char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
+                    *reinterpret_cast<half4*>(frag + out_off) = hh;
+                    *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
+                }
             }
         } else {
             // ---- the board's activations (conv1's output) out of the group layout into LDS
@@ -175,30 +186,32 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
             }
         }
         __syncthreads();
+        // slab = (32-channel block kb, tap row ky): 3 taps x {high, low} weight fragments, streamed from L2 one slab ahead into the
+        // other register set while this slab's sweep multiplies -- across the layer boundary too: the last slab of a layer requests
+        // slab 0 of the NEXT layer, which then lands during the epilogue
+        half8 wA[2][3], wB[2][3];
+        auto load_w = [&](const TrunkHLayer& LL, int slab, half8 (&W)[2][3]) {
+            const __amdgpu_buffer_rsrc_t r_h = make_rsrc(LL.wh, 9u * NCI * NT * 1024u);
+            const __amdgpu_buffer_rsrc_t r_l = make_rsrc(LL.wl, 9u * NCI * NT * 1024u);
+            const int kb = (slab / 3) % NCI, ky = slab % 3;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ub = (((ky * 3 + kx) * NCI + kb) * NT + tile) * 1024;
+                W[0][kx] = buf_ld_h8(r_h, lane16, ub);
+                W[1][kx] = buf_ld_h8(r_l, lane16, ub);
+            }
+        };
+        load_w(a.layers[1], 0, wA);
 #pragma unroll 1
         for (int l = 1; l < a.nlayers; ++l) {
             const TrunkHLayer& L = a.layers[l];
+            const TrunkHLayer& Lnext = a.layers[l + 1 < a.nlayers ? l + 1 : l];
             const bool second = (l & 1) == 0;          // second conv of a ResBlock: + x
             const bool last = l + 1 == a.nlayers;
-            const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(L.wh, 9u * NCI * NT * 1024u);
-            const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(L.wl, 9u * NCI * NT * 1024u);
             const float4 sc = L.sc[tile * 4 + kq], sh = L.sh[tile * 4 + kq];
             f32x4 acc[BW];
 #pragma unroll
             for (int y = 0; y < BW; ++y) acc[y] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // slab = (32-channel block kb, tap row ky): 3 taps x {high, low} weight fragments, streamed from L2 one slab ahead
-            // into the other register set while this slab's sweep multiplies
-            half8 wA[2][3], wB[2][3];
-            auto load_w = [&](int slab, half8 (&W)[2][3]) {
-                const int kb = (slab / 3) % NCI, ky = slab % 3;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ub = (((ky * 3 + kx) * NCI + kb) * NT + tile) * 1024;
-                    W[0][kx] = buf_ld_h8(rs_wh, lane16, ub);
-                    W[1][kx] = buf_ld_h8(rs_wl, lane16, ub);
-                }
-            };
-            load_w(0, wA);
 #pragma unroll 1
             for (int kb2 = 0; kb2 < NCI; kb2 += 2) {
 #pragma unroll
@@ -206,7 +219,10 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                     const int kb = kb2 + s6 / 3, ky = s6 % 3;
                     half8 (&w)[2][3] = (s6 & 1) ? wB : wA;
                     half8 (&wn)[2][3] = (s6 & 1) ? wA : wB;
-                    if (AO_BKO != 4) load_w(kb2 * 3 + s6 + 1, wn);          // (the last slab of a layer re-requests slab 0: harmless, keeps the loop uniform)
+                    if (AO_BKO != 4 || (kb2 == 2 && s6 == 5)) {
+                        if (kb2 == 2 && s6 == 5) load_w(Lnext, 0, wn);   // (after the last layer: that layer's slab 0 again, never used)
+                        else load_w(L, kb2 * 3 + s6 + 1, wn);
+                    }
                     // input row r feeds output row y = r + 1 - ky; two output rows at a time so that consecutive MFMAs
                     // accumulate into different registers
                     constexpr int NP = (BW + 1) / 2;

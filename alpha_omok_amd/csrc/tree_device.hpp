@@ -533,6 +533,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
     int mode = 2;
     if (!is_active || done >= target) mode = 0;
     else if (prev == LS_WAIT || prev == LS_WAIT_ROOT) mode = 1;
+    else if (prev == LS_DESCEND) mode = 4;   // a descent paused by the level budget goes on (it does not sit out: the simulation is under way)
     else if (sit_n > 0) {
         // over-subscribed (more games than rows per simulation): this launch's share of the games sits out -- a window of
         // game indices that moves on by its own length with every launch, so every game sits out equally often and all of them
@@ -575,6 +576,19 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
 #pragma unroll
     for (int c = 0; c < NCH; ++c) path_n[c] = path_e[c] = 0;
     PosR lp;
+    bool paused = false;
+    if (mode == 4) {   // resume: the path so far back into the registers, the node reached from the slot behind it
+        depth = p.path_len[g];
+        const size_t pb = static_cast<size_t>(g) * p.maxd;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = lane + 64 * c;
+            const int dc = d < p.maxd ? d : p.maxd - 1;
+            path_n[c] = p.path_node[pb + dc];
+            path_e[c] = p.path_edge[pb + dc];
+        }
+        node = p.path_node[pb + depth];
+    }
     if (node < 0) {
         lp = pos_load(p.rootpos + g);
     } else {
@@ -687,7 +701,11 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
                 const int cv = read_lane(chv[c], esel & 63), av = read_lane(static_cast<int>(acv[c]), esel & 63);
                 if ((esel >> 6) == c) { ch = cv; a = av; }
             }
-            if (ch >= 0) { node = ch; continue; }
+            if (ch >= 0) {
+                node = ch;
+                if (p.max_levels > 0 && static_cast<int>(levels) >= p.max_levels) { paused = true; break; }   // (level budget of this launch)
+                continue;
+            }
             if (ch == CH_TERMINAL) { status = LS_TERMINAL; break; }
             // first visit of this child: build its position, test for the end of the game
             lp = m;
@@ -703,7 +721,7 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
         }
     }
     AO_TT(8);
-    const bool to_expand = !failed && (status == LS_EXPAND || status == LS_EXPAND_ROOT);
+    const bool to_expand = !failed && !paused && (status == LS_EXPAND || status == LS_EXPAND_ROOT);
     bool wait = false;
     if (p.live) {   // the leaf's row in this simulation's batch (every wave of the workgroup gets here or to one of the take(false) above)
         batch_row = take(to_expand);
@@ -721,6 +739,18 @@ __device__ __forceinline__ void select_game(const TreeParams& p, const int g, ui
             p.path_node[static_cast<size_t>(g) * p.maxd + d] = path_n[c];
             p.path_edge[static_cast<size_t>(g) * p.maxd + d] = static_cast<int16_t>(path_e[c]);
         }
+    }
+    if (paused) {
+        if (lane == 0) {
+            p.path_node[static_cast<size_t>(g) * p.maxd + depth] = node;
+            p.leaf_status[g] = LS_DESCEND;
+            p.path_len[g] = depth;
+            unsigned* st = p.stats + static_cast<size_t>(g) * 4;
+            atomicAdd(st + 0, levels);
+            atomicAdd(st + 1, ties);
+        }
+        mt.close();
+        return;
     }
     if (to_expand) {
         lp.nchild = 0;
@@ -915,7 +945,7 @@ __device__ __forceinline__ void expand_backup_game(const TreeParams& p, const in
         hdr->prev_status = status;
         hdr->valid = 1;
     }
-    if (status == LS_IDLE || status == LS_WAIT || status == LS_WAIT_ROOT) return;   // (a waiting leaf: see select_game)
+    if (status == LS_IDLE || status == LS_WAIT || status == LS_WAIT_ROOT || status == LS_DESCEND) return;   // (a waiting leaf / a paused descent: see select_game)
     float v = 0.f;
     if (status == LS_EXPAND || status == LS_EXPAND_ROOT) {
         if (newn >= p.cap) {

@@ -1,5 +1,7 @@
 """-m gpu: the reference-shaped Python surface (agents.ZeroAgent, main.self_play) on the HIP engine
 against golden vectors captured from the reference and against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,59 @@ def test_carry_over_self_play_returns_each_calls_own_episodes():
     with pytest.raises(ValueError):
         main.self_play(3, seeds=[1, 2, 3])
     main.configure(board_size=B, n_mcts=S, n_blocks=2, out_planes=128, seed=0, reproducible=False, strict=False, carry_over=False)
+    main.release_engine()
+
+
+def test_over_subscribed_self_play_plays_the_same_episodes():
+    """configure(oversubscribe=1.5): 72 game slots on 48 rows of the evaluation batch -- the tree kernel hands out the rows per
+    simulation (terminal leaves take none), a share of the games sits out every launch, a leaf that finds the batch full is
+    evaluated one launch later -- and configure(rows='dynamic') without over-subscription. Every game still runs the reference's
+    strictly sequential search, so with one kernel family (reproducible=True) each episode must be the game its seed fixes: the
+    same cur_memory, results and replay as the per-move packing on 48 slots, with refills (100 episodes), on a TRAINED network
+    (terminal leaves inside the batches: tests/golden/trained_2block_9x9.npz)."""
+    import sys
+    import torch
+    import alpha_omok_amd.main as main
+    from alpha_omok_amd.pvnet import PVNet
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from make_trained_fixture import load
+    sd = load(os.path.join(REPO, "tests", "golden", "trained_2block_9x9.npz"))
+    B, S, N = 9, 64, 100
+
+    def run(over, rows):
+        model = PVNet(2, 5, 128, B)
+        model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+        main.MAX_CONCURRENT = 48
+        main.configure(board_size=B, n_mcts=S, n_blocks=2, in_planes=5, out_planes=128, seed=60, model=model.cuda().eval(), reproducible=True,
+                       node_cap=0, strict=True, carry_over=False, oversubscribe=over, rows=rows)
+        main.result.update(Black=0, White=0, Draw=0)
+        main.rep_memory.clear()
+        main.cur_memory.clear()
+        ret = main.self_play(N)
+        assert ret['episodes'] == N
+        eng = main._engine
+        info = (eng.G, eng.row_stats(), dict(main.search_totals))
+        out = [(s.copy(), p.copy(), z) for s, p, z in main.cur_memory]
+        res = dict(main.result)
+        main.MAX_CONCURRENT = 4096
+        return out, res, info
+
+    base, res0, (g0, rs0, st0) = run(1.0, 'static')
+    over, res1, (g1, rs1, st1) = run(1.5, 'auto')
+    dyn, res2, (g2, rs2, st2) = run(1.0, 'dynamic')
+    assert (g0, g1, g2) == (48, 72, 48)
+    assert rs0['launches'] == 0 and rs1['launches'] > 0 and rs2['launches'] > 0
+    shape = lambda st: tuple(st[k] for k in ('levels', 'ties', 'terminal', 'evaluated'))   # ('searches' = engine calls: follows the slot count)
+    assert st0['terminal'] > 0 and shape(st0) == shape(st1) == shape(st2)          # the same simulations, level for level
+    assert rs1['rows_live'] == st1['evaluated'] and rs2['rows_live'] == st2['evaluated'] and rs2['waits'] == 0
+    assert res0 == res1 == res2
+    for other in (over, dyn):
+        assert len(base) == len(other)
+        for (s0, p0, z0), (s1, p1, z1) in zip(base, other):
+            assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+    main.configure(board_size=B, n_mcts=S, n_blocks=2, out_planes=128, seed=0, reproducible=False, strict=False, carry_over=False,
+                   oversubscribe=1.0, rows='auto')
     main.release_engine()
 
 
