@@ -14,9 +14,11 @@
 //     MFMA on padding except the 16th cell (1.07 x the algorithmic MFMAs; k_layer16h<15> issues 15 x 18 / (15 x 15) = 1.2 x on its
 //     column tiles + halo);
 //   * wave w owns cout tile w (8 waves, two per SIMD) and keeps the accumulators of ALL 15 output rows (60 registers); the
-//     contraction runs slab-outermost: for each (32-channel input block, tap row) the wave has its 3 taps x {high, low} weight
-//     fragments in registers (streamed from L2 one slab ahead: every workgroup of the chip reads the same 590 KB per layer) and
-//     sweeps the board's rows -- 2 LDS reads, 4 DPP shifts and 9 MFMAs per (row, slab), no barrier inside a layer: the waves drift;
+//     contraction runs block-outermost: for each 32-channel input block the wave has its 9 taps x {high, low} weight fragments in
+//     registers (72; from L2: every workgroup of the chip reads the same 590 KB per layer) and sweeps the board's rows -- 2 LDS
+//     reads, 4 DPP shifts and 27 MFMAs per (row, block), no barrier inside a layer: the waves drift. (First form: weights streamed
+//     per (block, tap row) slab, double-buffered, 9 MFMAs per read + shift: 3 x the LDS reads and DPP moves per MFMA, 9 % slower --
+//     the chip is power-limited on this kernel, 2.1 of 2.4 GHz, and what the MFMAs do not need costs clock: profiles/r5o_*.)
 //   * layer boundary = barrier (everyone has read the input) -> epilogue (BatchNorm, residual, ReLU, split, 8-byte LDS writes in
 //     place) -> barrier. The ResBlock input of a wave's own cout tile stays in its registers (60) across the block's two convs;
 //   * conv1 runs in the same launch on the engine's bit planes (ao_search; 90 MFMAs per wave, K = tap * 8 + plane) -- or, for
@@ -30,8 +32,8 @@
 #pragma once
 
 // Timing knock-outs (-DAO_BKO=n, WRONG RESULTS, experiment builds only: AO_BUILD_TAG): 1 no DPP shifts (every tap column reads the
-// unshifted fragment), 2 the LDS fragments are read once per slab, 3 no epilogue (no LDS writes, no residual traffic), 4 weights of
-// slab 0 only, 5 no board load / write-back.
+// unshifted fragment), 3 no epilogue (no LDS writes), 4 the weights of a layer's block 0 only, 5 no board load. (Measured on the first,
+// slab-streamed form of the kernel: profiles/r5k_boardh_knockouts.txt.)
 #ifndef AO_BKO
 #define AO_BKO 0
 #endif
@@ -189,19 +191,18 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
         // slab = (32-channel block kb, tap row ky): 3 taps x {high, low} weight fragments, streamed from L2 one slab ahead into the
         // other register set while this slab's sweep multiplies -- across the layer boundary too: the last slab of a layer requests
         // slab 0 of the NEXT layer, which then lands during the epilogue
-        half8 wA[2][3], wB[2][3];
-        auto load_w = [&](const TrunkHLayer& LL, int slab, half8 (&W)[2][3]) {
+        half8 w9[2][9];
+        auto load_w9 = [&](const TrunkHLayer& LL, int kb) {
             const __amdgpu_buffer_rsrc_t r_h = make_rsrc(LL.wh, 9u * NCI * NT * 1024u);
             const __amdgpu_buffer_rsrc_t r_l = make_rsrc(LL.wl, 9u * NCI * NT * 1024u);
-            const int kb = (slab / 3) % NCI, ky = slab % 3;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ub = (((ky * 3 + kx) * NCI + kb) * NT + tile) * 1024;
-                W[0][kx] = buf_ld_h8(r_h, lane16, ub);
-                W[1][kx] = buf_ld_h8(r_l, lane16, ub);
+            for (int t = 0; t < 9; ++t) {
+                const int ub = ((t * NCI + kb) * NT + tile) * 1024;
+                w9[0][t] = buf_ld_h8(r_h, lane16, ub);
+                w9[1][t] = buf_ld_h8(r_l, lane16, ub);
             }
         };
-        load_w(a.layers[1], 0, wA);
+        load_w9(a.layers[1], 0);
 #pragma unroll 1
         for (int l = 1; l < a.nlayers; ++l) {
             const TrunkHLayer& L = a.layers[l];
@@ -212,56 +213,37 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
             f32x4 acc[BW];
 #pragma unroll
             for (int y = 0; y < BW; ++y) acc[y] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Block-outermost, all NINE taps of the block in registers (72, requested when the previous block's -- or, across the layer
+            // boundary, the previous layer's -- last row was done): an input row is read from LDS and shifted ONCE per block and feeds
+            // 27 MFMAs into the accumulators of output rows r + 1, r, r - 1 (consecutive MFMAs on different registers).
 #pragma unroll 1
-            for (int kb2 = 0; kb2 < NCI; kb2 += 2) {
+            for (int kb = 0; kb < NCI; ++kb) {
 #pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6) {           // two blocks x three tap rows: the buffer parity returns to wA
-                    const int kb = kb2 + s6 / 3, ky = s6 % 3;
-                    half8 (&w)[2][3] = (s6 & 1) ? wB : wA;
-                    half8 (&wn)[2][3] = (s6 & 1) ? wA : wB;
-                    if (AO_BKO != 4 || (kb2 == 2 && s6 == 5)) {
-                        if (kb2 == 2 && s6 == 5) load_w(Lnext, 0, wn);   // (after the last layer: that layer's slab 0 again, never used)
-                        else load_w(L, kb2 * 3 + s6 + 1, wn);
-                    }
-                    // input row r feeds output row y = r + 1 - ky; two output rows at a time so that consecutive MFMAs
-                    // accumulate into different registers
-                    constexpr int NP = (BW + 1) / 2;
+                for (int r = 0; r < BW; ++r) {
+                    half8 xh[3], xl[3];
+                    xh[1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 0) * 64 + lane]);
+                    xl[1] = __builtin_bit_cast(half8, s_x[((r * NCI + kb) * 2 + 1) * 64 + lane]);
+                    // tap column kx reads input cell (output cell + kx - 1): kx = 0 from the lane below, kx = 2 from the lane above
+                    xh[0] = AO_BKO == 1 ? xh[1] : dpp_shift_h8<kDppRowShr1>(xh[1]);
+                    xl[0] = AO_BKO == 1 ? xl[1] : dpp_shift_h8<kDppRowShr1>(xl[1]);
+                    xh[2] = AO_BKO == 1 ? xh[1] : dpp_shift_h8<kDppRowShl1>(xh[1]);
+                    xl[2] = AO_BKO == 1 ? xl[1] : dpp_shift_h8<kDppRowShl1>(xl[1]);
 #pragma unroll
-                    for (int yp = 0; yp < NP; ++yp) {
-                        half8 xh[2][3], xl[2][3];
+                    for (int pr = 0; pr < 3; ++pr) {          // products xh*wh, xh*wl, xl*wh
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int y = 2 * yp + j, r = y + ky - 1;
-                            if (y >= BW || r < 0 || r >= BW) continue;   // (uniform: rows off the board are skipped)
-                            const int rr = AO_BKO == 2 ? 0 : r;
-                            xh[j][1] = __builtin_bit_cast(half8, s_x[((rr * NCI + kb) * 2 + 0) * 64 + lane]);
-                            xl[j][1] = __builtin_bit_cast(half8, s_x[((rr * NCI + kb) * 2 + 1) * 64 + lane]);
-                            if (AO_BKO == 1) {
-                                xh[j][0] = xh[j][2] = xh[j][1];
-                                xl[j][0] = xl[j][2] = xl[j][1];
-                                continue;
-                            }
-                            // tap column kx reads input cell (output cell + kx - 1): kx = 0 from the lane below, kx = 2 from the lane above
-                            xh[j][0] = dpp_shift_h8<kDppRowShr1>(xh[j][1]);
-                            xl[j][0] = dpp_shift_h8<kDppRowShr1>(xl[j][1]);
-                            xh[j][2] = dpp_shift_h8<kDppRowShl1>(xh[j][1]);
-                            xl[j][2] = dpp_shift_h8<kDppRowShl1>(xl[j][1]);
-                        }
-                        // products xh*wh, xh*wl, xl*wh
+                        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-                        for (int pr = 0; pr < 3; ++pr) {
-#pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-                                for (int j = 0; j < 2; ++j) {
-                                    const int y = 2 * yp + j, r = y + ky - 1;
-                                    if (y >= BW || r < 0 || r >= BW) continue;
-                                    acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[pr == 1 ? 1 : 0][kx], pr == 2 ? xl[j][kx] : xh[j][kx], acc[y], 0, 0, 0);
-                                }
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const int y = r + 1 - ky;     // input row r = output row y + ky - 1; rows off the board are skipped (uniform)
+                                if (y < 0 || y >= BW) continue;
+                                acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w9[pr == 1 ? 1 : 0][ky * 3 + kx], pr == 2 ? xl[kx] : xh[kx], acc[y], 0, 0, 0);
                             }
                         }
-                        if (AO_BKO != 2) __builtin_amdgcn_sched_barrier(0);   // (keeps the LDS reads of the sweep from being hoisted to its top)
                     }
+                }
+                if (AO_BKO != 4) {
+                    if (kb + 1 < NCI) load_w9(L, kb + 1);
+                    else load_w9(Lnext, 0);                   // (after the last layer: its block 0 again, never used)
                 }
             }
             // ---- layer boundary: every wave has read the input; the output replaces it

@@ -41,6 +41,7 @@ def test_kernel_key_normalises_rocprof_and_library_names():
     assert bench.kernel_key("k_trunk16hb<9, 4> (conv1 + 8 3x3 convs ...)") == ("k_trunk16hb", "9")
     assert bench.kernel_key("k_trunk16h<9, 4>") != bench.kernel_key("k_trunk16hb<9, 4>")
     assert bench.kernel_key("k_layer16h<15> (one 3x3 conv per launch ...)") == bench.kernel_key("void ao::k_layer16h<15, 4, 4, 0>(ao::LayerHArgs)")
+    assert bench.kernel_key("k_boardh<15, 2> (conv1 + 20 3x3 convs ...)") == bench.kernel_key("void ao::k_boardh<15, 2>(ao::BoardHArgs)")
 
 
 def test_plan_kernel_follows_batch_size_and_input_kind():
@@ -49,7 +50,10 @@ def test_plan_kernel_follows_batch_size_and_input_kind():
     assert plan_kernel(10, 5, 128, 9, 4096, in_kind=2)[0].startswith("k_trunk16hb<9, 4, 0>")
     assert plan_kernel(4, 5, 128, 9, 1, in_kind=1)[0].startswith("k_conv_cells_h<9, 8>")
     assert plan_kernel(4, 5, 64, 9, 1, in_kind=1)[0].startswith("k_conv_cells<9>")
-    assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2)[0].startswith("k_layer16h<15>")
+    assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2)[0].startswith("k_boardh<15, 2>")     # wide boards, >= 128 of them: one board per workgroup, resident in LDS
+    assert plan_kernel(10, 5, 128, 15, 1024, in_kind=1)[0].startswith("k_boardh<15, 1>")
+    assert plan_kernel(10, 5, 128, 15, 100, in_kind=2)[0].startswith("k_layer16h<15>")
+    assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2, trunk_mode=6)[0].startswith("k_layer16h<15>")
     assert plan_kernel(4, 5, 128, 9, 1024, in_kind=2)[0].startswith("k_layer16hk<9, 4>")    # medium batch: cout-pair split
     assert plan_kernel(4, 5, 128, 9, 768, in_kind=2)[0].startswith("k_layer16hk<9, 4>")
     assert plan_kernel(4, 5, 128, 9, 2048, in_kind=2)[0].startswith("k_layer16h<9>")         # (the two-workgroup form is not planned by default)

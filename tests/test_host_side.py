@@ -414,3 +414,58 @@ def test_run_schedule_constants_scale_the_reference_loop(monkeypatch):
     finally:
         main.TRAIN_STEPS, main.BATCH_SIZE = None, 32
         main.rep_memory.clear(); main.cur_memory.clear()
+
+
+def test_configure_oversubscribe_and_rows_host_logic():
+    """Round 5 host logic of main.py, no GPU: configure(oversubscribe=, rows=) validation and persistence, the slot count of the
+    self-play engine (MAX_CONCURRENT rows x OVERSUBSCRIBE, never more than there are episodes), the carry-over default (None =
+    automatic inside run() with GAMES_PER_ITER) and the row mode `_set_rows` asks the engine for."""
+    import alpha_omok_amd.main as main
+    from alpha_omok_amd.pvnet import PVNet
+    keep = (main.MAX_CONCURRENT, main.OVERSUBSCRIBE, main.ROWS, main.CARRY_OVER)
+    try:
+        main.MAX_CONCURRENT = 4096
+        main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9), oversubscribe=1.25, rows='auto')
+        assert main.OVERSUBSCRIBE == 1.25 and main.ROWS == 'auto'
+        assert main._slots(10 ** 6) == 5120 and main._slots(3000) == 3000 and main._slots(1) == 1
+        main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9))   # unchanged by a call that does not name them
+        assert main.OVERSUBSCRIBE == 1.25
+        for bad in (0.5, 2.5):
+            with pytest.raises(ValueError):
+                main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), oversubscribe=bad)
+        with pytest.raises(ValueError):
+            main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), rows='sometimes')
+
+        class FakeEngine:
+            def __init__(self, G):
+                self.G, self.row_cap, self.calls = G, 0, []
+
+            def set_row_cap(self, cap):
+                self.row_cap = cap
+                self.calls.append(cap)
+
+        over, plain = FakeEngine(5120), FakeEngine(4096)
+        main._terminal_share = 0.0
+        main._set_rows(over)
+        main._set_rows(plain)
+        assert over.calls == [4096] and plain.calls == []            # over-subscribed: always per simulation; else static until leaves are terminal
+        main._terminal_share = 0.12
+        main._set_rows(plain)
+        main._set_rows(plain)
+        assert plain.calls == [4096]                                  # 'auto' switches once searches meet >= 3 % terminal leaves; no redundant calls
+        main._terminal_share = 0.0
+        main._set_rows(plain)
+        assert plain.calls == [4096, 0]
+        main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), rows='static')
+        main._terminal_share = 0.5
+        main._set_rows(plain)
+        assert plain.calls == [4096, 0]
+        main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), rows='dynamic', oversubscribe=1.0)
+        main._terminal_share = 0.0
+        main._set_rows(plain)
+        assert plain.calls == [4096, 0, 4096] and main._slots(10 ** 6) == 4096
+        assert main.CARRY_OVER is None or isinstance(main.CARRY_OVER, bool)
+    finally:
+        main.MAX_CONCURRENT = keep[0]
+        main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), oversubscribe=keep[1], rows=keep[2])
+        main.CARRY_OVER = keep[3]
