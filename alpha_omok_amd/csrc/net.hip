@@ -79,8 +79,9 @@ struct ao_net {
     bool attr_r[16] = {};
     // boards wider than 9: from this many boards on the trunk convs run as ONE launch of k_boardh (a workgroup = a board resident in
     // LDS through all layers, cells as the MFMA N dimension: net_board_h16.hpp); below it k_layer16h spreads a group over more
-    // workgroups than there are boards. AO_BOARDK=n overrides (0 = never).
-    int boardk_min = 128;
+    // workgroups than there are boards (15x15, 10 blocks, forward: 0.64 / 0.65 / 0.66 / 0.68 ms at 32 / 64 / 96 / 128 boards -- one board's
+    // time, the chip is not full -- against 0.60 / 0.67 / 0.82 / 0.88 for k_layer16h). AO_BOARDK=n overrides (0 = never).
+    int boardk_min = 64;
     bool attr_b[16] = {};
     // boards x cells up to which the per-board path is planned (boards of 4x4 .. 9x9, with k_row16hk behind it: 32 boards of 9x9 --
     // it was 96 before that kernel; AO_PERBOARD_CELLS)
@@ -629,7 +630,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                 a.layers[l].sh = reinterpret_cast<const float4*>(n->conv_sh[l]);
                 a.layers[l].ovf = n->d_status;
             }
-            const dim3 grid(std::min(boards, n->num_cu)), block(512);
+            // (the kernel deals boards to workgroups in rounds of 8 groups -- a group's 16 boards on one XCD --, so the grid covers whole rounds)
+            const dim3 grid(std::min((boards + 127) / 128 * 128, n->num_cu)), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
             switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \

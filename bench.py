@@ -678,6 +678,14 @@ def main():
                 tj = json.load(f)
             same_load = (G == 4096 and B == 9 and args.blocks == 4 and args.planes == 128 and S == 400)
             traffic, tree_traffic, traffic_why = match_traffic(tj, kname, csrc_sha, same_load)
+            if traffic is None and not same_load and tj.get("csrc_sha16") == csrc_sha:
+                # the profile may carry records of other workloads collected in the same session (e.g. the configs[4] per-GPU shape)
+                for w in tj.get("other_workloads", []):
+                    wl = w.get("workload", {})
+                    if ((wl.get("board"), wl.get("games"), wl.get("blocks"), wl.get("planes")) == (B, G, args.blocks, args.planes)
+                            and kernel_key(w.get("kernel", "")) == kernel_key(kname)):
+                        traffic, traffic_why = w.get("hbm_bytes_per_launch"), None
+                        break
         except Exception as e:
             traffic, traffic_why = None, "profile unreadable: %r" % (e,)
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)

@@ -52,7 +52,7 @@ def test_plan_kernel_follows_batch_size_and_input_kind():
     assert plan_kernel(4, 5, 64, 9, 1, in_kind=1)[0].startswith("k_conv_cells<9>")
     assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2)[0].startswith("k_boardh<15, 2>")     # wide boards, >= 128 of them: one board per workgroup, resident in LDS
     assert plan_kernel(10, 5, 128, 15, 1024, in_kind=1)[0].startswith("k_boardh<15, 1>")
-    assert plan_kernel(10, 5, 128, 15, 100, in_kind=2)[0].startswith("k_layer16h<15>")
+    assert plan_kernel(10, 5, 128, 15, 50, in_kind=2)[0].startswith("k_layer16h<15>")
     assert plan_kernel(10, 5, 128, 15, 1024, in_kind=2, trunk_mode=6)[0].startswith("k_layer16h<15>")
     assert plan_kernel(4, 5, 128, 9, 1024, in_kind=2)[0].startswith("k_layer16hk<9, 4>")    # medium batch: cout-pair split
     assert plan_kernel(4, 5, 128, 9, 768, in_kind=2)[0].startswith("k_layer16hk<9, 4>")
