@@ -153,8 +153,8 @@ def test_fused_search_trained_net_through_the_planner_boundaries_vs_oracle(oracl
     net.close()
 
 
-@pytest.mark.parametrize("G,PLIES,CAP,mode", [(1024, 13, 640, 6), (4096, 9, 3072, 0)])
-def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulation_rows(G, PLIES, CAP, mode):
+@pytest.mark.parametrize("BB,SS,G,PLIES,CAP,mode", [(9, 400, 1024, 13, 640, 6), (9, 400, 4096, 9, 3072, 0), (10, 48, 160, 44, 112, 0)])
+def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulation_rows(BB, SS, G, PLIES, CAP, mode):
     """One arithmetic for every batch size (ao_net_set_mode 6) makes a game's evaluations independent of who else is in the
     batch, so FOUR ways of running the same 1024 games must agree for EVERY game at every ply, bit for bit:
       A  ao_search, rows packed per move by the host (rounds 3 - 4),
@@ -165,11 +165,22 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
     13 plies of the trained network with games ending and being retired.
     Second case: 4096 games in the default mode, where all four run the RESIDENT trunk (k_trunk16hb / k_trunk16h, >= 192 groups;
     its result for a board does not depend on the board's row or neighbours either): the kernel of the headline, reading the live-row
-    count (C, D: 3072 rows = 192 groups for 4096 games)."""
+    count (C, D: 3072 rows = 192 groups for 4096 games).
+    Third case: a WIDE board (10x10, default-initialised 2-block network, 160 games, 44 plies): all four run k_boardh -- one board per
+    workgroup, conv1 on bit planes (A, C, D) or on float planes through k_layer16h (B): the same bits --, C and D with the kernel
+    reading the live-row count (112 rows for 160 games)."""
     import torch
     from alpha_omok_amd.engine import Engine, Net
-    net = Net(2, 5, 128, B, 0)
-    net.load_state_dict(_trained_state_dict())
+    B, S = BB, SS
+    if B == 9:
+        net = Net(2, 5, 128, B, 0)
+        net.load_state_dict(_trained_state_dict())
+    else:
+        from alpha_omok_amd.engine import plan_kernel
+        from alpha_omok_amd.pvnet import PVNet
+        torch.manual_seed(10)
+        net = PVNet(2, 5, 128, B).eval().to_native(0)
+        assert plan_kernel(2, 5, 128, B, CAP, in_kind=2)[0].startswith("k_boardh<%d, 2>" % B)
     net.set_mode(mode)
     seeds = np.arange(52000, 52000 + G, dtype=np.uint32)
     engs = {}
@@ -189,9 +200,11 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
         if not alive.any():
             break
         on = alive != 0
-        if mode == 0:
+        if mode == 0 and B == 9:
             assert int(on.sum()) >= 3072 + 16, "the resident trunk needs 192 groups: shorten the test"
-        tau = np.full(G, 1 if t < 6 else 0, np.int8)
+        if B != 9 and int(on.sum()) < 64:
+            break                                                         # (below 64 boards the planner leaves k_boardh)
+        tau = np.full(G, 1 if t < (6 if B == 9 else 30) else 0, np.int8)
         out = {}
         for name in "ACD":
             out[name] = engs[name].search(net, tau=tau, active=alive)
