@@ -179,7 +179,8 @@ int ao_row_stats(ao_engine *e, int64_t *launches, int64_t *rows_live, int64_t *r
  * and the value at the game's row of the evaluation batch, the number of simulations the game has completed, and its leaf
  * status (1 / 2: the leaf waits for exactly this evaluation; 3: terminal leaf, no evaluation -- the reference evaluates and
  * discards; 0 / 4 / 5: nothing of this game was evaluated in this launch). Launches beyond capacity_floats are not recorded;
- * n == 0 switches the log off. ao_eval_log_count: the launches recorded so far. */
+ * n == 0 switches the log off; dev_log must stay valid until then (or until ao_destroy). ao_eval_log_count: the launches
+ * recorded so far. */
 int ao_set_eval_log(ao_engine *e, const int32_t *host_games, int32_t n, float *dev_log, int64_t capacity_floats);
 int ao_eval_log_count(ao_engine *e);
 

@@ -252,6 +252,71 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
     net.close()
 
 
+def test_over_subscribed_handful_of_games_on_the_per_board_path_vs_oracle(oracle):
+    """Over-subscription at the small end: 40 games on 24 rows. The planner takes the per-board network path for 24 boards
+    (k_conv_cells_h + k_heads_board, not the fused per-game step: that one keeps the per-move packing), the tree kernel hands
+    out the rows, games sit out / leaves wait. Five sampled games against the oracle from the recorded evaluations (records of
+    launches in which a game did nothing are skipped by their leaf status), every game against the size-independent properties."""
+    import torch
+    from alpha_omok_amd.engine import Engine, Net
+    G, CAP, S_, PLIES = 40, 24, 48, 8
+    net = Net(2, 5, 128, B, 0)
+    net.load_state_dict(_trained_state_dict())
+    assert _kernel_family(2, CAP) == "k_conv_cells_h"
+    eng = Engine(B, S_, 5, games=G, noise=True)
+    eng.set_row_cap(CAP)
+    seeds = np.arange(61000, 61000 + G, dtype=np.uint32)
+    eng.seed_all(seeds)
+    sample = [0, 7, 23, 24, G - 1]
+    log = torch.zeros((4 * (S_ + 8) * len(sample) * (A + 3),), dtype=torch.float32, device="cuda")
+    cur = {g: [0] for g in sample}
+    recs = {g: [] for g in sample}
+
+    def make_agent(g):
+        def replay(moves, pl, sim, g=g):
+            i = cur[g][0]
+            cur[g][0] += 1
+            return recs[g][i]
+        ag = oracle.Agent(B, S_, 5, noise=True, evaluator=replay)
+        ag.seed(int(seeds[g]))
+        return ag
+
+    agents = {g: make_agent(g) for g in sample}
+    roots = {g: (0,) for g in sample}
+    inherited = np.zeros(G)
+    for t in range(PLIES):
+        tau = np.full(G, 1, np.int8)
+        eng.set_eval_log(sample, log.data_ptr(), log.numel())
+        pi, vis, pol = eng.search(net, tau=tau)
+        n_rec = eng.eval_log_count()
+        assert n_rec > S_ + (1 if t == 0 else 0), "40 games on 24 rows need more launches than simulations"
+        rec = log[:n_rec * len(sample) * (A + 3)].cpu().numpy().reshape(n_rec, len(sample), A + 3)
+        np.testing.assert_array_equal(vis.sum(axis=1), inherited + S_)
+        act, win = eng.play()
+        assert np.all(win == 0)
+        for k, g in enumerate(sample):
+            tag = "game %d ply %d" % (g, t)
+            recs[g] = _evals_of(rec, k)
+            cur[g][0] = 0
+            assert len(recs[g]) == S_ + (1 if t == 0 else 0), tag
+            opi, ovis, opol = agents[g].get_pi(roots[g], 1)
+            np.testing.assert_array_equal(vis[g], ovis, err_msg=tag)
+            np.testing.assert_array_equal(pol[g], opol, err_msg=tag)
+            np.testing.assert_array_equal(pi[g], opi, err_msg=tag)
+            oa = agents[g].rng.choice_p(opi)
+            assert act[g] == oa, tag
+            roots[g] = roots[g] + (int(oa),)
+            mt, pos, _, _ = eng.get_rng_state(g)
+            assert pos == agents[g].rng.pos, tag
+            np.testing.assert_array_equal(mt, agents[g].rng.state_words(), err_msg="mt " + tag)
+        inherited = vis[np.arange(G), act] - 1
+    rs = eng.row_stats()
+    assert rs["launches"] > PLIES * S_ and rs["rows_live"] <= rs["rows_launched"]
+    eng.set_eval_log([])
+    eng.close()
+    net.close()
+
+
 def test_self_play_with_the_trained_network_replayed_by_the_oracle(oracle):
     """main.self_play(n) -- the whole drop-in loop: Evaluator export of the trained PVNet, ao_search with the planner following
     the shrinking number of active games (k_row16hk -> per-board path), get_action, env step, re-rooting -- with three

@@ -48,6 +48,9 @@ def main():
                     help="game slots per row of the 4096-row evaluation batch (main.configure: 1.25 = 5120 resident games; terminal leaves "
                          "take no row, the extra games fill what they leave). 1 = as many games as rows")
     ap.add_argument("--rows", default="auto", choices=("auto", "static", "dynamic"))
+    ap.add_argument("--rows-per-sim", type=int, default=None,
+                    help="rows of the evaluation batch = leaves evaluated per simulation (main.MAX_CONCURRENT; default 4096). BASELINE configs[4]'s "
+                         "per-GPU shape is 1024 (15x15: 256 workgroups of k_boardh x 4 boards)")
     ap.add_argument("--eval-every", type=int, default=5)
     ap.add_argument("--eval-matches", type=int, default=64)
     ap.add_argument("--eval-sims", type=int, default=None)
@@ -74,6 +77,8 @@ def main():
         print(json.dumps(rec), flush=True)
 
     m.BATCH_SIZE, m.LR, m.L2, m.MEMORY_SIZE, m.TRAIN_STEPS = a.batch, a.lr, a.l2, a.memory, a.steps
+    if a.rows_per_sim:
+        m.MAX_CONCURRENT = a.rows_per_sim
     m.configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, out_planes=a.planes, seed=a.seed,
                 device_replay=True, carry_over=not a.no_carry_over, oversubscribe=a.oversubscribe, rows=a.rows)
     if a.resume:
