@@ -545,6 +545,7 @@ def main():
     ap.add_argument("--trained-weights", default=TRAINED_CKPT, help="state_dict of a trained 9x9 / 4-block / 128-plane PVNet for the `trained_net` leg")
     ap.add_argument("--oversubscribe", type=float, default=1.25, help="`trained_net` leg: games per row of the evaluation batch (1.25: 5120 games on "
                     "the 4096 rows per simulation the tree kernel hands out; 1: the per-move packing only)")
+    ap.add_argument("--no-wide-board", action="store_true", help="skip the `wide_board` leg (BASELINE configs[4]'s per-GPU shape: 15x15, 10 blocks, 800 sims, 1024 games)")
     ap.add_argument("--no-trained-net", action="store_true", help="skip the `trained_net` leg (the headline workload with trained weights)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -817,6 +818,46 @@ def main():
         # (the main engine's trees -- 124 GB of arena at 4096 games -- are not needed by any leg below: free them before the
         # legs that build engines of their own)
         eng.close()
+        if world == 1 and not args.no_wide_board and (B, G, S) == (9, 4096, 400) and args.planes == 128:
+            # BASELINE configs[4]'s per-GPU shape beside the headline: 15x15 (env_regular), 10-block net, 800 sims, 1024 concurrent games
+            # (8192 games on 8 GPUs = 1024 per GPU); 1 untimed + 2 timed move decisions from the empty board. Kernel: k_boardh<15, 2>.
+            try:
+                from alpha_omok_amd.engine import Engine
+                Bw, Gw, Sw = 15, 1024, 800
+                torch.manual_seed(0)
+                mw = PVNet(10, 5, args.planes, Bw)
+                mw.eval()
+                netw = mw.to_native(local)
+                engw = Engine(Bw, Sw, 5, games=Gw, noise=True, device=local)
+                engw.seed_all(np.arange(11 * Gw, 12 * Gw, dtype=np.uint32))
+
+                def wstep():
+                    engw.search(netw, tau=np.ones(Gw, np.int8))
+                    engw.play()
+                wstep()
+                netw.conv_timing(True)
+                engw.sync()
+                torch.cuda.synchronize()
+                tw0 = time.perf_counter()
+                nw = 2
+                for _ in range(nw):
+                    wstep()
+                engw.sync()
+                torch.cuda.synchronize()
+                dw = time.perf_counter() - tw0
+                cw_ms, cw_n = netw.conv_timing(False)
+                kw, fw = netw.dominant_kernel(Gw)
+                aw = cw_ms / max(cw_n, 1)
+                out["wide_board"] = {"workload": "BASELINE configs[4] per-GPU shape: 15x15 Omok, %d concurrent games, %d sims/move, random-init 10-block/%d-ch PVNet" % (Gw, Sw, args.planes),
+                                     "value": nw * Gw / dw, "unit": "move-decisions/s", "ms_per_step": dw / nw * 1e3, "steps": nw,
+                                     "flops_per_move_algorithmic": Sw * eval_flops(Bw, 5, args.planes, 10),
+                                     "roofline": {"bound": "mfma", "kernel": kw.split(" (")[0], "flop_per_launch": fw, "avg_launch_ms": aw, "launches_timed": cw_n,
+                                                  "achieved": fw / (aw * 1e-3) / 1e12 if cw_n else 0.0, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": fw / (aw * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if cw_n else 0.0}}
+                engw.close()
+                netw.close()
+            except Exception as e:
+                out["wide_board"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_trained_net and os.path.exists(args.trained_weights) and (B, args.blocks, args.planes) == (9, 4, 128):
             try:
                 out["trained_net"] = trained_net_bench(args, local, args.trained_weights, oversubscribe=args.oversubscribe)

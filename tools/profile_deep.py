@@ -26,7 +26,7 @@ tag = argv[0] if argv else "r1x"
 out = os.path.join(REPO, "gpurun_out", "profiles_" + tag)
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block", "--no-tictactoe",
+cmd = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block", "--no-tictactoe", "--no-wide-board",
        "--steps", "1", "--warmup", "0", "--sims", "20"] + BENCH_ARGS
 if CMD:
     cmd = shlex.split(CMD)

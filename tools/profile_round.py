@@ -27,7 +27,7 @@ def prof(name, extra, cmd):
     return dbs[0] if dbs else None
 
 
-bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block", "--no-tictactoe", "--no-trained-net"]
+bench = ["python", os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-single-game", "--no-fp32-compare", "--no-ten-block", "--no-tictactoe", "--no-trained-net", "--no-wide-board"]
 db = prof("stats", ["--stats"], bench + ["--steps", "2", "--warmup", "1"])
 with open(os.path.join(out, tag + "_kernel_stats.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-game --no-fp32-compare --no-ten-block\n")
