@@ -25,17 +25,19 @@ class Evaluator:
 
     def native_net(self, model, board_size, inplanes):
         cfg = pvnet.looks_like_pvnet(model)
-        if cfg is not None and (cfg[2] % 32 or cfg[2] > 256) and cfg[3] == board_size and cfg[1] == inplanes:
-            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward is built for multiples of 32 up to 256
+        if cfg is not None and pvnet.native_width(cfg[2]) % 32 and cfg[3] == board_size and cfg[1] == inplanes:
+            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward covers up to 256 (other widths zero-padded to
+            # the next multiple of 32, pvnet.pad_state_dict)
             if not self._warned_width:
                 import warnings
-                warnings.warn("PVNet with %d planes: the native MI355X forward covers multiples of 32 planes up to 256 -- this network "
+                warnings.warn("PVNet with %d planes: the native MI355X forward covers up to 256 planes -- this network "
                               "is evaluated by its own torch module, one call per simulation on the whole leaf batch "
                               "(correct, but several times slower than the MFMA kernels)" % cfg[2], RuntimeWarning, stacklevel=3)
                 self._warned_width = True
             return None
-        if cfg is None or cfg[2] % 32 or cfg[2] > 256 or cfg[3] != board_size or cfg[1] != inplanes:
+        if cfg is None or pvnet.native_width(cfg[2]) % 32 or cfg[3] != board_size or cfg[1] != inplanes:
             return None
+        width = pvnet.native_width(cfg[2])
         # the native copy is keyed on the module OBJECT (held through a weak reference: a new module
         # at a recycled address is a different object), its shape and the in-place version counters of
         # its tensors; invalidate() forces a re-export for anything those cannot see
@@ -46,9 +48,10 @@ class Evaluator:
             if self._net is None or self._cfg != cfg:
                 if self._net is not None:
                     self._net.close()
-                self._net = Net(cfg[0], cfg[1], cfg[2], cfg[3], self.device)
+                self._net = Net(cfg[0], cfg[1], width, cfg[3], self.device)
                 self._cfg = cfg
-            self._net.load_state_dict(model.state_dict())
+            sd = model.state_dict()
+            self._net.load_state_dict(sd if width == cfg[2] else pvnet.pad_state_dict(sd, width))
             self._net.set_mode(self.net_mode)             # after every export, 0 included: an fp16-range fallback of the OLD weights ends here
             self._key = (cfg, version)
             try:

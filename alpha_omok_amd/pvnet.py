@@ -72,13 +72,55 @@ class PVNet(nn.Module):
         return self.policy_head(t), self.value_head(t)
 
     def to_native(self, device=0, net=None):
-        """Export the current weights to the HIP forward. Returns an alpha_omok_amd.engine.Net."""
+        """Export the current weights to the HIP forward. Returns an alpha_omok_amd.engine.Net. Widths that are not a multiple of
+        32 (model.py:76-85 takes any `planes`) are exported zero-padded to the next multiple (`pad_state_dict`): same function."""
         from .engine import Net
         n_block, inplanes, planes, board_size = self.cfg
+        width = native_width(planes)
         if net is None:
-            net = Net(n_block, inplanes, planes, board_size, device)
-        net.load_state_dict(self.state_dict())
+            net = Net(n_block, inplanes, width, board_size, device)
+        sd = self.state_dict()
+        net.load_state_dict(sd if width == planes else pad_state_dict(sd, width))
         return net
+
+
+def native_width(planes):
+    """The width the HIP forward runs a `planes`-wide network at: the next multiple of 32 (at most 256), or `planes` itself when
+    the native kernels cannot take it (wider than 256: the caller's torch module evaluates it)."""
+    width = (int(planes) + 31) // 32 * 32
+    return width if 32 <= width <= 256 else int(planes)
+
+
+def pad_state_dict(state_dict, width):
+    """PVNet state_dict of `planes` channels -> the state_dict of the SAME function at `width` >= planes channels: the extra channels
+    have zero conv weights and identity BatchNorm statistics (mean 0, variance 1, shift 0), so they carry exact zeros through the
+    ReLUs and the skips; the 1x1 head convs, value_fc1 (its hidden width is `planes` too) and value_fc2 get zero columns / rows
+    for them. Every added term of every sum is +0.0: the outputs are those of the unpadded network up to the order of summation."""
+    import numpy as np
+    out = {}
+    for k, v in state_dict.items():
+        a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        name = k.split(".")[-1]
+        if k.endswith("conv1.weight") and k == "conv1.weight":
+            p = np.zeros((width,) + a.shape[1:], a.dtype); p[:a.shape[0]] = a
+        elif name == "weight" and a.ndim == 4 and a.shape[2] == 3:                 # trunk convs [planes, planes, 3, 3]
+            p = np.zeros((width, width) + a.shape[2:], a.dtype); p[:a.shape[0], :a.shape[1]] = a
+        elif name == "weight" and a.ndim == 4:                                    # 1x1 head convs [2 | 1, planes, 1, 1]
+            p = np.zeros((a.shape[0], width) + a.shape[2:], a.dtype); p[:, :a.shape[1]] = a
+        elif k == "value_head.value_fc1.weight":                                  # [planes, cells]
+            p = np.zeros((width, a.shape[1]), a.dtype); p[:a.shape[0]] = a
+        elif k == "value_head.value_fc1.bias":
+            p = np.zeros((width,), a.dtype); p[:a.shape[0]] = a
+        elif k == "value_head.value_fc2.weight":                                  # [1, planes]
+            p = np.zeros((1, width), a.dtype); p[:, :a.shape[1]] = a
+        elif a.ndim == 1 and name in ("weight", "bias", "running_mean", "running_var") and "policy_bn" not in k and "value_bn" not in k \
+                and "fc" not in k:
+            fill = 1.0 if name in ("weight", "running_var") else 0.0              # trunk BatchNorms [planes]
+            p = np.full((width,), fill, a.dtype); p[:a.shape[0]] = a
+        else:
+            p = a
+        out[k] = p
+    return out
 
 
 def looks_like_pvnet(module):

@@ -708,3 +708,44 @@ def test_board_resident_trunk_wide_boards_vs_torch_and_per_layer(nb, B, batch):
     assert torch.equal(p, p2) and torch.equal(v, v2)
     net.close()
     net_l.close()
+
+
+@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 100, 300), (1, 7, 40, 33), (2, 9, 200, 64), (2, 15, 100, 70)])
+def test_widths_that_are_not_a_multiple_of_32_run_natively_zero_padded(nb, B, planes, batch):
+    """model.PVNet takes any `planes` (model.py:76-85). Round 5: widths up to 256 that are not a multiple of 32 are exported
+    zero-padded to the next multiple (pvnet.pad_state_dict) and run on the same MFMA kernels -- 100 planes on the split-fp16
+    kernels at 128, 200 on the fp32-MFMA layer kernels at 224 -- instead of falling back to the torch module; through
+    PVNet.to_native and through the engine's Evaluator (no warning, a native Net). Against torch fp32 within 1e-4."""
+    import warnings
+    import torch
+    from alpha_omok_amd.evaluator import Evaluator
+    from alpha_omok_amd.pvnet import PVNet, native_width
+    torch.manual_seed(planes + nb)
+    ref = PVNet(nb, 5, planes, B)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    ref.eval()
+    rs = np.random.RandomState(batch)
+    x = (rs.rand(batch, 5, B, B) < 0.3).astype(np.float32)
+    with torch.no_grad():
+        rp, rv = ref(torch.from_numpy(x))
+    net = ref.to_native(0)
+    assert net.planes == native_width(planes) and net.planes % 32 == 0
+    p, v = net(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    dp, dv = np.abs(p.cpu().numpy() - rp.numpy()).max(), np.abs(v.cpu().numpy() - rv.numpy()).max()
+    assert dp < TOL and dv < TOL, (dp, dv)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ev = Evaluator(0)
+        n2 = ev.native_net(ref.cuda(), B, 5)
+    assert n2 is not None and n2.planes == native_width(planes)
+    p2, v2 = n2(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p) and torch.equal(v2, v)
+    net.close()

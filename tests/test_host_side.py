@@ -469,3 +469,34 @@ def test_configure_oversubscribe_and_rows_host_logic():
         main.MAX_CONCURRENT = keep[0]
         main.configure(board_size=9, n_blocks=1, out_planes=32, model=PVNet(1, 5, 32, 9), oversubscribe=keep[1], rows=keep[2])
         main.CARRY_OVER = keep[3]
+
+
+def test_pad_state_dict_keeps_the_function():
+    """pvnet.pad_state_dict: a PVNet of any width (model.py:76-85) as the SAME function at the next multiple of 32 channels -- how
+    widths the MFMA kernels are not built for reach the native forward (zero conv weights + identity BatchNorm statistics for the
+    extra channels, zero columns / rows in the heads). torch on both: equal up to the order of summation."""
+    import torch
+    from alpha_omok_amd.pvnet import PVNet, native_width, pad_state_dict
+    assert [native_width(p) for p in (20, 32, 33, 100, 128, 130, 250, 256, 300)] == [32, 32, 64, 128, 128, 160, 256, 256, 300]
+    for nb, planes, B in ((2, 100, 9), (1, 40, 7), (3, 130, 5)):
+        torch.manual_seed(planes)
+        m = PVNet(nb, 5, planes, B)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.uniform_(-0.2, 0.2)
+                    mod.running_var.uniform_(0.5, 1.5)
+                    mod.weight.uniform_(0.5, 1.5)
+                    mod.bias.uniform_(-0.2, 0.2)
+        m.eval()
+        width = native_width(planes)
+        big = PVNet(nb, 5, width, B)
+        sd = pad_state_dict(m.state_dict(), width)
+        assert set(sd) == set(big.state_dict()) and all(tuple(sd[k].shape) == tuple(v.shape) for k, v in big.state_dict().items())
+        big.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        big.eval()
+        x = (torch.rand(6, 5, B, B) < 0.3).float()
+        with torch.no_grad():
+            p0, v0 = m(x)
+            p1, v1 = big(x)
+        assert float((p0 - p1).abs().max()) < 1e-6 and float((v0 - v1).abs().max()) < 1e-6
