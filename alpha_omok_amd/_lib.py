@@ -48,6 +48,7 @@ SYMBOLS = {
     "ao_sync": (C.c_int, [_vp]),
     "ao_seed": (C.c_int, [_vp, C.c_int, C.c_uint32]),
     "ao_seed_all": (C.c_int, [_vp, _u32p]),
+    "ao_seed_games": (C.c_int, [_vp, _i32p, _u32p, C.c_int32]),
     "ao_get_rng_state": (C.c_int, [_vp, C.c_int, _u32p, _i32p, _i32p, _f64p]),
     "ao_set_rng_state": (C.c_int, [_vp, C.c_int, _u32p, C.c_int32, C.c_int32, C.c_double]),
     "ao_reset": (C.c_int, [_vp, _u8p]),

@@ -383,6 +383,26 @@ int ao_seed(ao_engine* e, int g, uint32_t seed) {
     return ao_set_rng_state(e, g, mt.data(), 624, 0, 0.0);
 }
 
+int ao_seed_games(ao_engine* e, const int32_t* games, const uint32_t* seeds, int32_t n) {
+    AO_HIP(e, hipSetDevice(e->cfg.device));
+    if (n <= 0) return 0;
+    for (int k = 0; k < n; ++k)
+        if (games[k] < 0 || games[k] >= e->G) return e->fail("ao_seed_games: game index out of range");
+    AO_HIP(e, hipStreamSynchronize(e->stream));   // (the pinned staging rows are free)
+    for (int k = 0; k < n; ++k) {
+        const int g = games[k];
+        ao::HostMT::seed(e->h_mt + static_cast<size_t>(g) * 624, seeds[k]);
+        e->h_pos[g] = 624;
+        e->has_gauss[g] = 0;
+        e->gauss[g] = 0.0;
+        AO_HIP(e, hipMemcpyAsync(e->tp.mt + static_cast<size_t>(g) * 624, e->h_mt + static_cast<size_t>(g) * 624, sizeof(uint32_t) * 624,
+                                 hipMemcpyHostToDevice, e->stream));
+        AO_HIP(e, hipMemcpyAsync(e->tp.mtpos + g, e->h_pos + g, sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    }
+    AO_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 int ao_seed_all(ao_engine* e, const uint32_t* seeds) {
     AO_HIP(e, hipSetDevice(e->cfg.device));
     AO_HIP(e, hipStreamSynchronize(e->stream));

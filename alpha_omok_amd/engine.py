@@ -168,6 +168,14 @@ class Engine:
         assert s.size == self.G
         self._check(self._L.ao_seed_all(self._h, _ptr(s, C.c_uint32)), "ao_seed_all")
 
+    def seed_games(self, games, seeds):
+        """seed() for the listed games with one synchronisation (ao_seed_games)."""
+        g = np.ascontiguousarray(games, np.int32)
+        s = np.ascontiguousarray(np.asarray(seeds, np.uint64) & 0xFFFFFFFF, np.uint32)
+        assert g.size == s.size
+        if g.size:
+            self._check(self._L.ao_seed_games(self._h, _ptr(g, C.c_int32), _ptr(s, C.c_uint32), int(g.size)), "ao_seed_games")
+
     def get_rng_state(self, game):
         mt = np.zeros(624, np.uint32)
         pos, hg, gs = C.c_int32(0), C.c_int32(0), C.c_double(0)

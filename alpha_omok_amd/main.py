@@ -308,8 +308,8 @@ def _play_episodes(episodes, use_global, seed_of):
                 ply[g] = 0
             if refill.any():
                 eng.reset(refill)                         # Agent.reset() (main.py:248)
-                for g in np.flatnonzero(refill):
-                    eng.seed(int(g), seed_of(episodes[slot_row[g]]))
+                gs = np.flatnonzero(refill)
+                eng.seed_games(gs, [seed_of(episodes[slot_row[g]]) for g in gs])
     _check_trim(eng)
     if trace is not None:
         last_trace[:] = trace
@@ -388,8 +388,8 @@ def _play_carry(first_episode, n_call, rank, world):
             pool.slot_id[g] = gid
         if mask.any():
             eng.reset(mask)                               # Agent.reset() (main.py:248)
-            for g in np.flatnonzero(mask):
-                eng.seed(int(g), seed_of(int(pool.slot_id[g])))
+            gs = np.flatnonzero(mask)
+            eng.seed_games(gs, [seed_of(int(pool.slot_id[g])) for g in gs])
             pool.active[mask != 0] = 1
             pool.ply[mask != 0] = 0
             pool.slot_moves[mask != 0] = -1

@@ -427,9 +427,9 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
                 c["games"] += int(done.sum())
             if done.any():
                 eng.reset(done.astype(np.uint8))
-                for g in np.nonzero(done)[0]:
-                    eng.seed(int(g), nxt[0])
-                    nxt[0] += 1
+                gs = np.nonzero(done)[0]
+                eng.seed_games(gs, np.arange(nxt[0], nxt[0] + gs.size))
+                nxt[0] += gs.size
                 ply[done] = 0
 
         for _ in range(warm_plies):
@@ -612,9 +612,9 @@ def main():
             counters["games"] += int(done.sum())
         if done.any():  # refill finished slots with fresh games (Agent.reset(), main.py:248)
             eng.reset(done.astype(np.uint8))
-            for g in np.nonzero(done)[0]:
-                eng.seed(int(g), next_seed[0])
-                next_seed[0] += world
+            gs = np.nonzero(done)[0]
+            eng.seed_games(gs, next_seed[0] + world * np.arange(gs.size))
+            next_seed[0] += world * gs.size
             ply[done] = 0
 
     train_on = args.train_step == "on" or (args.train_step == "auto" and world > 1)

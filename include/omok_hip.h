@@ -68,6 +68,8 @@ int  ao_set_stream(ao_engine *e, void *stream);
  * ao_seed == np.random.seed(seed) for game g (MT19937 init_genrand, pos 624, no cached gauss). */
 int ao_seed(ao_engine *e, int game, uint32_t seed);
 int ao_seed_all(ao_engine *e, const uint32_t *host_seeds /*[G]*/);
+/* ao_seed for the n listed games with ONE synchronisation (the refill of finished self-play slots: main.py:248 + np.random.seed per episode) */
+int ao_seed_games(ao_engine *e, const int32_t *host_games, const uint32_t *host_seeds, int32_t n);
 int ao_get_rng_state(ao_engine *e, int game, uint32_t *host_mt /*[624]*/, int32_t *pos,
                      int32_t *has_gauss, double *gauss);
 int ao_set_rng_state(ao_engine *e, int game, const uint32_t *host_mt, int32_t pos,

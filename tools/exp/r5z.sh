@@ -3,7 +3,7 @@
 python -m pytest tests -m gpu -x -q > gpurun_out/r5z_pytest.log 2>&1; tail -3 gpurun_out/r5z_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > gpurun_out/r5z_bench.json 2> gpurun_out/r5z_bench.err; tail -c 900 gpurun_out/r5z_bench.json; echo
-python bench.py --no-trained-net --no-ten-block --no-fp32-compare --no-single-game --no-tictactoe > gpurun_out/r5z_bench_again.json 2> /dev/null
+python bench.py --no-trained-net --no-ten-block --no-fp32-compare --no-single-game --no-tictactoe --no-wide-board > gpurun_out/r5z_bench_again.json 2> /dev/null
 python -c "
 import json
 for f in ('r5z_bench.json', 'r5z_bench_again.json'):
