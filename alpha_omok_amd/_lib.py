@@ -94,6 +94,8 @@ SYMBOLS = {
     "ao_replay_clear": (C.c_int, [_vp]),
     "ao_replay_extend": (C.c_int, [_vp, _P(C.c_float), _f64p, _P(C.c_float), C.c_int64, C.c_int, _vp]),
     "ao_replay_extend_skip": (C.c_int, [_vp, _P(C.c_float), _f64p, _P(C.c_float), C.c_int64, C.c_int, C.c_int64, _vp]),
+    "ao_replay_extend_moves": (C.c_int, [_vp, _P(C.c_int16), C.c_int64, C.c_int64, _P(C.c_int32), _P(C.c_int32), _f64p, _P(C.c_float),
+                                         C.c_int64, C.c_int, C.c_int64, _vp]),
     "ao_replay_gather": (C.c_int, [_vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
     "ao_replay_read": (C.c_int, [_vp, C.c_int64, C.c_int64, _f64p, _f64p, _f64p]),
     "ao_rollout_create": (C.c_int, [_P(AoRolloutConfig), _P(_vp)]),

@@ -240,6 +240,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.B = c.board; p.A = A; p.Ap = Ap; p.C = c.inplanes; p.win_mark = c.win_mark; p.G = G;
     p.cap = c.node_cap; p.maxd = A + 2; p.noise = c.noise ? 1 : 0;
     p.keep_max = c.node_cap - c.sims - 1;
+    p.compact_always = getenv("AO_COMPACT_ALWAYS") != nullptr;   // developer switch: re-root by copying after every move (rounds 1 - 5)
     p.nchq = (((c.inplanes + 3) / 4) + 7) & ~7;  // worst case of the network's input layouts (net_plan)
     p.nchq_live = p.nchq;
     p.il_group = ao::kGroup;
@@ -270,7 +271,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         dev_alloc(e, &p.rootpos, G) || dev_alloc(e, &p.mt, static_cast<size_t>(G) * 624) ||
         dev_alloc(e, &p.mtpos, G) || dev_alloc(e, &p.noise_buf, static_cast<size_t>(G) * Ap) ||
         dev_alloc(e, &p.sims_target, G) || dev_alloc(e, &p.sims_done, G) || dev_alloc(e, &p.gflags, G) ||
-        dev_alloc(e, &p.rstatus, G) || dev_alloc(e, &p.leaf_status, G) || dev_alloc(e, &p.path_len, G) ||
+        dev_alloc(e, &p.rstatus, G) || dev_alloc(e, &p.pending_root, G) || dev_alloc(e, &p.leaf_status, G) || dev_alloc(e, &p.path_len, G) ||
         dev_alloc(e, &p.path_node, static_cast<size_t>(G) * p.maxd) ||
         dev_alloc(e, &p.path_edge, static_cast<size_t>(G) * p.maxd) || dev_alloc(e, &p.leaf_pos, G) ||
         dev_alloc(e, &p.err, G) || dev_alloc(e, &p.trimmed, static_cast<size_t>(G) * 2) || dev_alloc(e, &p.stats, static_cast<size_t>(G) * 4) ||
@@ -1078,19 +1079,30 @@ int ao_tree_nodes(ao_engine* e, int g, int64_t* expanded, int64_t* dict_entries)
     if (g < 0 || g >= e->G) return e->fail("game index out of range");
     AO_HIP(e, hipSetDevice(e->cfg.device));
     AO_HIP(e, hipStreamSynchronize(e->stream));
-    int32_t cur = 0, used = 0;
+    int32_t cur = 0, used = 0, root = -1;
     AO_HIP(e, hipMemcpy(&cur, e->tp.cur + g, 4, hipMemcpyDeviceToHost));
     AO_HIP(e, hipMemcpy(&used, e->tp.nodes_used + g, 4, hipMemcpyDeviceToHost));
-    if (expanded) *expanded = used;
-    if (dict_entries) {
-        std::vector<ao::Pos> metas(used);
-        // (the positions sit at the end of their node records: a strided copy)
-        if (used) AO_HIP(e, hipMemcpy2D(metas.data(), sizeof(ao::Pos), ao::nodePos(e->tp, ao::node_slot(e->tp, cur, g, 0)), e->tp.rec,
-                                        sizeof(ao::Pos), used, hipMemcpyDeviceToHost));
-        int64_t t = used ? 1 : 0;
-        for (const ao::Pos& m : metas) t += m.nchild;
-        *dict_entries = t;
+    AO_HIP(e, hipMemcpy(&root, e->tp.root_node + g, 4, hipMemcpyDeviceToHost));
+    // What the root reaches (what del_parents would leave): the arena may also hold nodes of earlier roots that no search can reach
+    // any more -- it is compacted only when the next search needs their room (k_play) -- so the records in use are walked from the root.
+    int64_t nodes = 0, entries = 0;
+    if (used > 0 && root >= 0) {
+        std::vector<unsigned char> recs(static_cast<size_t>(used) * e->tp.rec);
+        AO_HIP(e, hipMemcpy(recs.data(), ao::node_rec(e->tp, ao::node_slot(e->tp, cur, g, 0)), recs.size(), hipMemcpyDeviceToHost));
+        std::vector<int32_t> queue{root};
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const unsigned char* rec = recs.data() + static_cast<size_t>(queue[head]) * e->tp.rec;
+            const ao::Pos* m = reinterpret_cast<const ao::Pos*>(rec + 25u * e->tp.Ap);
+            const int32_t* ch = reinterpret_cast<const int32_t*>(rec + 16u * e->tp.Ap);
+            entries += m->nchild;
+            for (int i = 0; i < m->nchild; ++i)
+                if (ch[i] >= 0 && ch[i] < used && queue.size() < static_cast<size_t>(used)) queue.push_back(ch[i]);
+        }
+        nodes = static_cast<int64_t>(queue.size());
+        entries += 1;
     }
+    if (expanded) *expanded = nodes;
+    if (dict_entries) *dict_entries = entries;
     return 0;
 }
 

@@ -67,6 +67,41 @@ __global__ void k_replay_write(const float* __restrict__ s_in, const double* __r
     }
 }
 
+// Device-side sample emission (reference main.py:159-166, 219-227 builds every sample's state with utils.get_state_pt,
+// utils.py:139-168, one Python call per ply): sample i is the position of episode ep_of[i] after t = ply_of[i] of its moves.
+// One workgroup per sample: `when[cell]` = 1-based ply that put a stone on the cell (0: empty at that time), then plane
+// C-2-j holds X_{t-j}, the stones of the mover of ply t-j after that ply (same colour as that ply, placed no later), and plane
+// C-1 the colour to move (1.0 when black is to move). Writes the staged float32 states k_replay_write then spreads.
+__global__ __launch_bounds__(128) void k_states_from_moves(const short* __restrict__ moves, int L, const int* __restrict__ ep_of,
+                                                           const int* __restrict__ ply_of, long n, float* __restrict__ s_out,
+                                                           int C, int A) {
+    __shared__ short when[256];
+    for (long smp = blockIdx.x; smp < n; smp += gridDim.x) {
+        const int t = ply_of[smp];
+        const short* mv = moves + static_cast<long>(ep_of[smp]) * L;
+        for (int c = threadIdx.x; c < A; c += blockDim.x) when[c] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < t; i += blockDim.x) {
+            const int m = mv[i];
+            if (m >= 0 && m < A) when[m] = static_cast<short>(i + 1);
+        }
+        __syncthreads();
+        float* out = s_out + smp * C * A;
+        for (int idx = threadIdx.x; idx < C * A; idx += blockDim.x) {
+            const int plane = idx / A, cell = idx - plane * A;
+            bool one;
+            if (plane == C - 1) {
+                one = (t & 1) == 0;
+            } else {
+                const int p = t - (C - 2 - plane), w = when[cell];
+                one = p >= 1 && w >= 1 && w <= p && ((w ^ p) & 1) == 0;
+            }
+            out[idx] = one ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
 // mini-batch: out_s [m][C][A] f32, out_pi [m][A] f32 (the reference's .float()), out_z [m] f32
 __global__ void k_replay_gather(const float* __restrict__ s_ring, const double* __restrict__ pi_ring,
                                 const float* __restrict__ z_ring, const long* __restrict__ slots, long m,
@@ -100,6 +135,8 @@ struct ao_replay {
     // staging (grow-only)
     float* st_s = nullptr; double* st_pi = nullptr; float* st_z = nullptr; long* st_idx = nullptr;
     int64_t st_n = 0, st_m = 0;
+    short* st_mv = nullptr; int* st_ep = nullptr; int* st_ply = nullptr;   // moves-based extend: episodes' moves, (episode, ply) per sample
+    int64_t st_mv_n = 0, st_ep_n = 0;
     std::string err;
     int fail(const std::string& m) { err = m; return 1; }
 };
@@ -143,7 +180,8 @@ void ao_replay_destroy(ao_replay* r) {
     hipSetDevice(r->device);
     for (void* p : {static_cast<void*>(r->s_ring), static_cast<void*>(r->pi_ring), static_cast<void*>(r->z_ring),
                     static_cast<void*>(r->st_s), static_cast<void*>(r->st_pi), static_cast<void*>(r->st_z),
-                    static_cast<void*>(r->st_idx)})
+                    static_cast<void*>(r->st_idx), static_cast<void*>(r->st_mv), static_cast<void*>(r->st_ep),
+                    static_cast<void*>(r->st_ply)})
         if (p) hipFree(p);
     delete r;
 }
@@ -161,8 +199,12 @@ int ao_replay_clear(ao_replay* r) {
 
 // `skipped` samples logically precede the n given ones in this call but are not supplied: the caller knows that every
 // entry of theirs would be overwritten by the given ones (n * nsym >= capacity), so only ring positions move for them.
-static int extend_impl(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
-                       int64_t skipped, void* stream) {
+struct MoveSource {   // states == nullptr: the states are built on the device from the episodes' moves
+    const int16_t* moves; int64_t n_ep; int64_t L; const int32_t* ep_of; const int32_t* ply_of;
+};
+
+static int extend_impl(ao_replay* r, const float* states, const MoveSource* mv, const double* pi, const float* z, int64_t n,
+                       int augment, int64_t skipped, void* stream) {
     if (n < 0 || skipped < 0) return r->fail("ao_replay_extend: negative sample count");
     if (n == 0 && skipped == 0) return 0;
     const int nsym = augment ? 8 : 1;
@@ -189,7 +231,34 @@ static int extend_impl(ao_replay* r, const float* states, const double* pi, cons
         RP_HIP(r, hipMalloc(&r->st_z, static_cast<size_t>(n_st) * sizeof(float)));
         r->st_n = n_st;
     }
-    RP_HIP(r, hipMemcpyAsync(r->st_s, states + first_smp * CA, static_cast<size_t>(n_st) * CA * sizeof(float), hipMemcpyHostToDevice, s));
+    if (mv) {
+        if (mv->n_ep < 1 || mv->L < 1 || mv->L > r->A) return r->fail("ao_replay_extend_moves: n_episodes >= 1 and 1 <= max_len <= board * board");
+        for (int64_t i = first_smp; i < n; ++i)
+            if (mv->ep_of[i] < 0 || mv->ep_of[i] >= mv->n_ep || mv->ply_of[i] < 0 || mv->ply_of[i] > mv->L)
+                return r->fail("ao_replay_extend_moves: sample " + std::to_string(i) + " names an episode or a ply outside the moves given");
+        const int64_t nmv = mv->n_ep * mv->L;
+        if (nmv > r->st_mv_n) {
+            if (r->st_mv) hipFree(r->st_mv);
+            r->st_mv = nullptr; r->st_mv_n = 0;
+            RP_HIP(r, hipMalloc(&r->st_mv, static_cast<size_t>(nmv) * sizeof(short)));
+            r->st_mv_n = nmv;
+        }
+        if (n_st > r->st_ep_n) {
+            if (r->st_ep) hipFree(r->st_ep);
+            if (r->st_ply) hipFree(r->st_ply);
+            r->st_ep = nullptr; r->st_ply = nullptr; r->st_ep_n = 0;
+            RP_HIP(r, hipMalloc(&r->st_ep, static_cast<size_t>(n_st) * sizeof(int)));
+            RP_HIP(r, hipMalloc(&r->st_ply, static_cast<size_t>(n_st) * sizeof(int)));
+            r->st_ep_n = n_st;
+        }
+        RP_HIP(r, hipMemcpyAsync(r->st_mv, mv->moves, static_cast<size_t>(nmv) * sizeof(short), hipMemcpyHostToDevice, s));
+        RP_HIP(r, hipMemcpyAsync(r->st_ep, mv->ep_of + first_smp, static_cast<size_t>(n_st) * sizeof(int), hipMemcpyHostToDevice, s));
+        RP_HIP(r, hipMemcpyAsync(r->st_ply, mv->ply_of + first_smp, static_cast<size_t>(n_st) * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ao::k_states_from_moves, dim3(static_cast<unsigned>(std::min<int64_t>(n_st, 65535L * 16))), dim3(128), 0, s,
+                           r->st_mv, static_cast<int>(mv->L), r->st_ep, r->st_ply, static_cast<long>(n_st), r->st_s, r->C, r->A);
+    } else {
+        RP_HIP(r, hipMemcpyAsync(r->st_s, states + first_smp * CA, static_cast<size_t>(n_st) * CA * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     RP_HIP(r, hipMemcpyAsync(r->st_pi, pi + first_smp * r->A, static_cast<size_t>(n_st) * r->A * sizeof(double), hipMemcpyHostToDevice, s));
     RP_HIP(r, hipMemcpyAsync(r->st_z, z + first_smp, static_cast<size_t>(n_st) * sizeof(float), hipMemcpyHostToDevice, s));
     const int64_t tail = (r->head + r->count + (skipped % r->cap) * nsym) % r->cap;  // slot of the first given entry
@@ -225,12 +294,19 @@ static int extend_impl(ao_replay* r, const float* states, const double* pi, cons
 
 int ao_replay_extend(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
                      void* stream) {
-    return extend_impl(r, states, pi, z, n, augment, 0, stream);
+    return extend_impl(r, states, nullptr, pi, z, n, augment, 0, stream);
 }
 
 int ao_replay_extend_skip(ao_replay* r, const float* states, const double* pi, const float* z, int64_t n, int augment,
                           int64_t skipped, void* stream) {
-    return extend_impl(r, states, pi, z, n, augment, skipped, stream);
+    return extend_impl(r, states, nullptr, pi, z, n, augment, skipped, stream);
+}
+
+int ao_replay_extend_moves(ao_replay* r, const int16_t* moves, int64_t n_episodes, int64_t max_len, const int32_t* ep_of,
+                           const int32_t* ply_of, const double* pi, const float* z, int64_t n, int augment, int64_t skipped,
+                           void* stream) {
+    const MoveSource mv{moves, n_episodes, max_len, ep_of, ply_of};
+    return extend_impl(r, nullptr, &mv, pi, z, n, augment, skipped, stream);
 }
 
 int ao_replay_gather(ao_replay* r, const int64_t* idx, int64_t m, float* dev_states, float* dev_pi, float* dev_z,

@@ -180,59 +180,115 @@ __global__ __launch_bounds__(64) void k_end_move(TreeParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// re-rooting: copy the subtree of `old_node` into the other arena (breadth first), so the arena
-// holds only what later searches can reach. Reads the old arena only; the BFS queue lives in LDS.
+// re-rooting: copy the subtree of the node k_play / k_walk chose (p.pending_root) into the other arena, breadth first, so the
+// arena holds only what later searches can reach. Reads the old arena only; the BFS queue lives in LDS.
+// One workgroup of kRerootWaves waves per game. With a network that has learned something the played child keeps most of the
+// root's visits -- subtrees of one to two thousand nodes -- and a copy that takes one node per memory round trip (rounds 1 - 5:
+// one wave per game inside k_play) lasted 12.5 ms per move of 4096 games (tools/time_move_phases.py --weights ...). Here wave w
+// takes queue entry head + w: the record reads of kRerootWaves nodes are in flight together, the children's new indices come from
+// a prefix over the waves' child counts, in queue order -- the SAME numbering as the one-node-at-a-time copy, entry for entry.
 // ----------------------------------------------------------------------------------------------
+constexpr int kRerootWaves = 8;
+
 template <int NCH>
-__device__ void reroot(const TreeParams& p, int g, int old_node, int32_t* s_old) {
+__global__ __launch_bounds__(64 * kRerootWaves) void k_reroot(TreeParams p, const int32_t* games) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    int32_t* s_cnt = reinterpret_cast<int32_t*>(s_dyn);        // [kRerootWaves] children each wave's node brings, [kRerootWaves] dropped
+    int32_t* s_old = s_cnt + 2 * kRerootWaves;                 // [cap] old index of the node that becomes new index i
+    const int g = games ? games[blockIdx.x] : blockIdx.x;
+    const int pend = p.pending_root[g];
+    if (pend == 0) return;                                     // (uniform over the workgroup)
     const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
     const int oa = p.cur[g];
     const int na = oa ^ 1;
-    if (lane == 0) s_old[0] = old_node;
+    if (threadIdx.x == 0) s_old[0] = pend - 1;
+    if (lane == 0) s_cnt[kRerootWaves + w] = 0;
     __syncthreads();
     int tail = 1;
     int dropped = 0;
-    for (int head = 0; head < tail; ++head) {
-        const int o = s_old[head];
-        const size_t so = node_slot(p, oa, g, o);
-        const size_t sn = node_slot(p, na, g, head);
-        const PosR m = pos_load(nodePos(p, so));
-        const int L = m.nchild;
+    for (int head = 0; head < tail;) {
+        const int h = head + w;
+        const bool have = h < tail;                            // (wave-uniform) this round takes queue entries [head, min(head + waves, tail))
+        const int next_head = head + kRerootWaves < tail ? head + kRerootWaves : tail;
+        size_t so = 0;
+        PosR m;
+        int ch[NCH], nn[NCH];
+        uint8_t act[NCH];
+        float ww[NCH], qq[NCH];
+        double pp[NCH];
+        bool valid[NCH];
+        int cnt = 0;
+        if (have) {
+            so = node_slot(p, oa, g, s_old[h]);
+            m = pos_load(nodePos(p, so));
+            const int L = m.nchild;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int e = lane + 64 * c;
-            const bool valid = e < L;
-            const int ch = valid ? rowCH(p, so)[e] : CH_UNVISITED;
-            const bool ex = valid && ch >= 0;
-            const uint64_t mk = __ballot(ex);
-            const int idx = tail + __popcll(mk & lanes_below());
-            // A full arena (a long game whose visits keep following the played line): the breadth-first copy stops at
-            // keep_max nodes, so the next move's expansions always fit. A child subtree that is not kept becomes an
-            // unvisited child again (its statistics are forgotten); the event is counted in p.trimmed (ao_trim_stats).
-            const bool keep = ex && idx < p.keep_max;
-            const bool drop = ex && !keep;
-            if (keep) s_old[idx] = ch;
-            if (valid) {
-                rowCH(p, sn)[e] = keep ? idx : (drop ? CH_UNVISITED : ch);
-                rowN(p, sn)[e] = drop ? 0 : rowN(p, so)[e];
-                rowW(p, sn)[e] = drop ? 0.f : rowW(p, so)[e];
-                rowQ(p, sn)[e] = drop ? 0.f : rowQ(p, so)[e];
-                rowP(p, sn)[e] = rowP(p, so)[e];
-                rowACT(p, sn)[e] = rowACT(p, so)[e];
+            for (int c = 0; c < NCH; ++c) {
+                const int e = lane + 64 * c;
+                valid[c] = e < L;
+                ch[c] = valid[c] ? rowCH(p, so)[e] : CH_UNVISITED;
+                nn[c] = valid[c] ? rowN(p, so)[e] : 0;
+                ww[c] = valid[c] ? rowW(p, so)[e] : 0.f;
+                qq[c] = valid[c] ? rowQ(p, so)[e] : 0.f;
+                pp[c] = valid[c] ? rowP(p, so)[e] : 0.0;
+                act[c] = valid[c] ? rowACT(p, so)[e] : 0;
+                cnt += __popcll(__ballot(valid[c] && ch[c] >= 0));
             }
-            const int kept = __popcll(__ballot(keep));
-            dropped += __popcll(mk) - kept;
-            tail += kept;
         }
-        if (lane == 0) pos_store(nodePos(p, sn), m);
+        if (lane == 0) s_cnt[w] = cnt;
+        __syncthreads();
+        int base = tail, total = 0;
+#pragma unroll
+        for (int k = 0; k < kRerootWaves; ++k) {
+            const int ck = s_cnt[k];
+            if (k < w) base += ck;
+            total += ck;
+        }
+        if (have) {
+            const size_t sn = node_slot(p, na, g, h);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int e = lane + 64 * c;
+                const bool ex = valid[c] && ch[c] >= 0;
+                const uint64_t mk = __ballot(ex);
+                const int idx = base + __popcll(mk & lanes_below());
+                // A full arena (a long game whose visits keep following the played line): the breadth-first copy stops at
+                // keep_max nodes, so the next move's expansions always fit. A child subtree that is not kept becomes an
+                // unvisited child again (its statistics are forgotten); the event is counted in p.trimmed (ao_trim_stats).
+                const bool keep = ex && idx < p.keep_max;
+                const bool drop = ex && !keep;
+                if (keep) s_old[idx] = ch[c];
+                if (valid[c]) {
+                    rowCH(p, sn)[e] = keep ? idx : (drop ? CH_UNVISITED : ch[c]);
+                    rowN(p, sn)[e] = drop ? 0 : nn[c];
+                    rowW(p, sn)[e] = drop ? 0.f : ww[c];
+                    rowQ(p, sn)[e] = drop ? 0.f : qq[c];
+                    rowP(p, sn)[e] = pp[c];
+                    rowACT(p, sn)[e] = act[c];
+                }
+                dropped += __popcll(__ballot(drop));
+                base += __popcll(mk);
+            }
+            if (lane == 0) pos_store(nodePos(p, sn), m);
+        }
+        // (indices handed out in queue order: everything below keep_max is kept, so the queue grows by what fits)
+        const int room = p.keep_max - tail;
+        tail += total < room ? total : (room > 0 ? room : 0);
+        head = next_head;
         __syncthreads();
     }
-    if (lane == 0) {
+    if (lane == 0 && dropped > 0) s_cnt[kRerootWaves + w] = dropped;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int d = 0;
+        for (int k = 0; k < kRerootWaves; ++k) d += s_cnt[kRerootWaves + k];
         p.nodes_used[g] = tail;
         p.cur[g] = na;
         p.root_node[g] = 0;
-        if (dropped > 0) {
-            p.trimmed[2 * g] += dropped;
+        p.pending_root[g] = 0;
+        if (d > 0) {
+            p.trimmed[2 * g] += d;
             p.trimmed[2 * g + 1] += 1;
         }
     }
@@ -246,7 +302,6 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     uint32_t* s_mt = reinterpret_cast<uint32_t*>(s_dyn);             // 624 * 4 = 2496 B
     double* s_cdf = reinterpret_cast<double*>(s_dyn + 2496);         // 256 * 8 = 2048 B
-    int32_t* s_old = reinterpret_cast<int32_t*>(s_dyn + 2496 + 2048);  // cap * 4
     const int g = blockIdx.x;
     const int lane = lane_id();
     if (p.active && !p.active[g]) return;
@@ -295,7 +350,15 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
         if (found >= 0) ch = rowCH(p, slot)[found];
     }
     if (ch >= 0 && w == 0) {
-        reroot<NCH>(p, g, ch, s_old);
+        // The arena is compacted (k_reroot, launched right behind this kernel: the subtree copied into the other arena) only when
+        // the next search might not fit behind what is in it: nodes_used <= keep_max = cap - sims - 1 leaves room for every
+        // expansion of the next move, so the root just moves to the child and the unreachable nodes stay where they are until a
+        // later move needs the room. Same trees, same trims (a subtree above keep_max nodes implies nodes_used above it), a
+        // copy every (cap - subtree) / sims moves instead of every move.
+        if (lane == 0) {
+            if (p.nodes_used[g] <= p.keep_max && !p.compact_always) p.root_node[g] = ch;
+            else p.pending_root[g] = ch + 1;
+        }
     } else if (lane == 0) {
         p.nodes_used[g] = 0;
         p.root_node[g] = -1;
@@ -320,8 +383,6 @@ __global__ __launch_bounds__(64) void k_play(TreeParams p) {
 template <int NCH>
 __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games, const int32_t* extra_all, int stride,
                                              const int32_t* m_all, const int32_t* prev_known_all, int32_t* status_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    int32_t* s_old = reinterpret_cast<int32_t*>(s_dyn);
     const int lane = lane_id();
     const int b = blockIdx.x;
     const int g = games[b];
@@ -361,7 +422,7 @@ __global__ __launch_bounds__(64) void k_walk(TreeParams p, const int32_t* games,
     int status = 0;
     if (node >= 0) {
         status = 2;
-        if (m > 0) reroot<NCH>(p, g, node, s_old);
+        if (m > 0 && lane == 0) p.pending_root[g] = node + 1;   // k_reroot (launch_walk) copies the subtree
     } else {
         status = known ? 1 : 0;
         if (lane == 0) { p.nodes_used[g] = 0; p.root_node[g] = -1; }
@@ -407,6 +468,7 @@ __global__ void k_reset(TreeParams p, const uint8_t* mask) {
     p.sims_target[g] = 0;
     p.err[g] = 0;
     p.leaf_status[g] = LS_IDLE;
+    p.pending_root[g] = 0;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -450,15 +512,20 @@ void launch_begin_move(const TreeParams& p, hipStream_t s) {
 void launch_end_move(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_end_move<NCH>, dim3(p.G), dim3(64), 0, s, p));
 }
+static void launch_reroot(const TreeParams& p, int count, const int32_t* games, hipStream_t s) {
+    const size_t lds = (2 * kRerootWaves + static_cast<size_t>(p.cap)) * 4;
+    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_reroot<NCH>, dim3(count), dim3(64 * kRerootWaves), lds, s, p, games));
+}
 void launch_play(const TreeParams& p, hipStream_t s) {
-    const size_t lds = 2496 + 2048 + static_cast<size_t>(p.cap) * 4;
+    const size_t lds = 2496 + 2048;
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_play<NCH>, dim3(p.G), dim3(64), lds, s, p));
+    launch_reroot(p, p.G, nullptr, s);
 }
 void launch_walk(const TreeParams& p, int count, const int32_t* games, const int32_t* extra, int stride, const int32_t* m,
                  const int32_t* prev_known, int32_t* status_out, hipStream_t s) {
-    const size_t lds = static_cast<size_t>(p.cap) * 4 + 16;
-    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_walk<NCH>, dim3(count), dim3(64), lds, s, p, games, extra, stride, m,
+    AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_walk<NCH>, dim3(count), dim3(64), 0, s, p, games, extra, stride, m,
                                                    prev_known, status_out));
+    launch_reroot(p, count, games, s);
 }
 void launch_eval_log(const int32_t* games, int n, const int32_t* row_of_game, const float* policy, const float* value, int A,
                      float* out, const int32_t* sims_done, const int32_t* leaf_status, int what, hipStream_t s) {

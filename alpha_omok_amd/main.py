@@ -63,7 +63,7 @@ GAMES_PER_ITER = None   # run(): games of every iteration after the first (None:
 TRAIN_STEPS = None      # train(): mini-batches per pass (None: the reference's len(cur_memory), main.py:263-264)
 
 rep_memory = deque(maxlen=MEMORY_SIZE)
-cur_memory = deque()
+cur_memory = utils.SampleQueue()   # the reference's deque (main.py:56) that can also hold a call's samples as ONE block (utils.LazySamples)
 step = 0
 skipped_steps = 0       # train_batch: mini-batches whose loss was not finite (one process only; see train_batch)
 start_iter = 0
@@ -84,9 +84,12 @@ last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of e
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 # search shape, cumulative since configure(): PUCT levels walked, exact-tie draws, terminal leaves, evaluated leaves over all
 # simulations of all searches (levels / (evaluated + terminal) = mean selection depth)
+phase_seconds = {'play': 0.0, 'emit': 0.0}   # cumulative since configure(): self_play's wall time inside the searches / building and appending the samples
 search_totals = {'levels': 0, 'ties': 0, 'terminal': 0, 'evaluated': 0, 'searches': 0}
 CARRY_OVER = None            # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
                              # (None = automatic: on inside run() when GAMES_PER_ITER is set, off otherwise)
+DEVICE_STATES = True         # with configure(device_replay=True): the samples' state planes are built on the device from the move lists
+                             # (ao_replay_extend_moves) and cur_memory's entries rebuild theirs on first access; False = host-built
 CARRY_CALLS = 2              # ... of at most this many calls ahead
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
 _terminal_share = 0.0        # terminal leaves / simulations of the last search (drives ROWS = 'auto')
@@ -134,6 +137,7 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     trim_stats['subtrees_dropped'] = trim_stats['reroots_trimmed'] = 0
     for k in search_totals:
         search_totals[k] = 0
+    phase_seconds['play'] = phase_seconds['emit'] = 0.0
     import torch
     from .pvnet import PVNet
     BOARD_SIZE = board_size or BOARD_SIZE
@@ -469,6 +473,7 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         return int(seeds[ep]) if seeds is not None else (SEED + first_episode + ep) & 0xFFFFFFFF
 
     A = BOARD_SIZE * BOARD_SIZE
+    t_play = time.perf_counter()
     try:
         if single_stream or (n_selfplay == 1 and seeds is None and world == 1):
             parts = [_play_episodes([ep], True, seed_of) for ep in episodes]   # sequential, each on the global stream where the last left it
@@ -499,6 +504,8 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         _pool = None
         raise
 
+    t_emit = time.perf_counter()
+    phase_seconds['play'] += t_emit - t_play
     # results and samples in episode order (main.py:201-227); samples arrive sorted by (episode, ply)
     result['Black'] += int((wins == 1).sum())
     result['White'] += int((wins == 2).sum())
@@ -506,6 +513,15 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     reward_black = np.where(wins == 1, 1., np.where(wins == 2, -1., 0.))
     z = np.where(ply_of % 2 == 0, reward_black[ep_of], -reward_black[ep_of])
     z = np.where(z == 0, 0., z)                           # (no -0.0: the reference's draw reward is +0.0 for both colours)
+    if DEVICE_STATES and hasattr(rep_memory, "extend_augmented_moves"):
+        # device-side sample emission: the replay memory builds the planes of utils.get_state_pt from the move lists in a kernel
+        # (ao_replay_extend_moves); cur_memory gets entries that rebuild their state only if somebody looks at it
+        n_new = int(ep_of.shape[0])
+        cur_memory.extend(utils.LazySamples(moves, ep_of, ply_of, pis, z, BOARD_SIZE, IN_PLANES))   # one block, no per-sample object
+        Agent.reset()
+        rep_memory.extend_augmented_moves(moves, ep_of, ply_of, pis, z)
+        phase_seconds['emit'] += time.perf_counter() - t_emit
+        return dict(episodes=len(episodes), moves=n_new, **trim_stats)
     states = utils.states_of_episodes(moves, ep_of, ply_of, BOARD_SIZE, IN_PLANES)
     n_new = states.shape[0]
     zl = z.tolist()
@@ -521,6 +537,7 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
             keep = min(n_new, -(-rep_memory.maxlen // 8))
         tail = [(states[i], pis[i], zl[i]) for i in range(n_new - keep, n_new)]
         rep_memory.extend(utils.augment_dataset(tail, BOARD_SIZE))
+    phase_seconds['emit'] += time.perf_counter() - t_emit
     return dict(episodes=len(episodes), moves=int(n_new), **trim_stats)
 
 

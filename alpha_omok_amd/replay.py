@@ -85,6 +85,32 @@ class DeviceReplay:
                                                   zz.ctypes.data_as(C.POINTER(C.c_float)), n - first, 1, first, None),
                     "ao_replay_extend_skip")
 
+    def extend_augmented_moves(self, moves, ep_of, ply_of, pi, z):
+        """extend_augmented_arrays without the states: sample i is the position of episode ep_of[i] after ply_of[i] of its
+        moves (moves [E, L] action indices, -1 padded) and the planes of utils.get_state_pt (utils.py:139-168) are built by a
+        kernel (ao_replay_extend_moves) -- nothing of size n x C x B x B exists on the host."""
+        n = int(np.shape(ep_of)[0])
+        if n == 0:
+            return
+        moves = np.asarray(moves)
+        if moves.ndim != 2 or tuple(np.shape(pi)[1:]) != (self.A,) or np.shape(ply_of)[0] != n or np.shape(pi)[0] != n or np.shape(z)[0] != n:
+            raise ReplayError("moves [E, L], ep_of / ply_of / z [n] and pi [n, %d] expected" % self.A)
+        cap = self.maxlen
+        first = 0
+        if 8 * n > cap:
+            first = max(0, n - (-(-cap // 8) + 1))
+            if 8 * (n - first) < cap:
+                first = 0
+        mv = np.ascontiguousarray(moves[:, :self.A], dtype=np.int16)
+        e = np.ascontiguousarray(ep_of[first:], dtype=np.int32)
+        t = np.ascontiguousarray(ply_of[first:], dtype=np.int32)
+        p = np.ascontiguousarray(pi[first:], dtype=np.float64)
+        zz = np.ascontiguousarray(z[first:], dtype=np.float32)
+        self._check(self._L.ao_replay_extend_moves(self._h, mv.ctypes.data_as(C.POINTER(C.c_int16)), mv.shape[0], mv.shape[1],
+                                                   e.ctypes.data_as(C.POINTER(C.c_int32)), t.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   p.ctypes.data_as(C.POINTER(C.c_double)), zz.ctypes.data_as(C.POINTER(C.c_float)),
+                                                   n - first, 1, first, None), "ao_replay_extend_moves")
+
     def read(self, first, n):
         s = np.empty((n, self.C, self.B, self.B), np.float64)
         pi = np.empty((n, self.A), np.float64)

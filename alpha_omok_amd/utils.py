@@ -108,6 +108,140 @@ def states_of_episodes(moves, ep_of, ply_of, board_size, channel_size, dtype=np.
     return out.reshape(N, channel_size, board_size, board_size)
 
 
+class LazySamples:
+    """The samples of one main.self_play call -- (state [C, B, B] f64, pi [A] f64, z float) as main.py:159-166 appends them --
+    without the states: they are rebuilt (states_of_episodes, all of the block at once) the first time anyone looks at one.
+    With rep_memory on the device the states are made there (ao_replay_extend_moves) and cur_memory is only ever counted,
+    so nothing of size n x C x B x B is built on the host. Iterating yields one tuple-like entry per sample."""
+
+    def __init__(self, moves, ep_of, ply_of, pis, z, board_size, channel_size):
+        self.moves, self.ep_of, self.ply_of, self.pis = moves, ep_of, ply_of, pis
+        self.z = np.asarray(z, dtype=np.float64).tolist()                     # Python floats, as the reference stores them
+        self.board_size, self.channel_size = board_size, channel_size
+        self._states = None
+
+    def __len__(self):
+        return len(self.z)
+
+    def states(self):
+        if self._states is None:
+            self._states = states_of_episodes(self.moves, self.ep_of, self.ply_of, self.board_size, self.channel_size)
+        return self._states
+
+    def __iter__(self):
+        return (LazySample(self, i) for i in range(len(self)))
+
+
+class SampleQueue:
+    """main.cur_memory: the reference's deque of (state, pi, z) tuples (main.py:56) -- len / iteration / indexing / append /
+    extend / pop / popleft / clear -- that can also take a whole LazySamples block by reference: extend(block) is O(1), no
+    per-sample object exists until somebody iterates or indexes (main.train only ever counts cur_memory)."""
+    maxlen = None
+
+    def __init__(self, iterable=()):
+        self._seg = []          # [block, lo, hi] (LazySamples, live range) or a plain list of entries
+        self.extend(iterable)
+
+    def __len__(self):
+        return sum(g[2] - g[1] if _is_block(g) else len(g) for g in self._seg)
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def _tail_list(self):
+        if not self._seg or _is_block(self._seg[-1]):
+            self._seg.append([])
+        return self._seg[-1]
+
+    def append(self, x):
+        self._tail_list().append(x)
+
+    def extend(self, iterable):
+        if isinstance(iterable, LazySamples):
+            if len(iterable):
+                self._seg.append(_Block((iterable, 0, len(iterable))))
+        else:
+            self._tail_list().extend(iterable)
+
+    def clear(self):
+        self._seg = []
+
+    def _drop_empty(self):
+        self._seg = [g for g in self._seg if (g[2] - g[1] if _is_block(g) else len(g)) > 0]
+
+    def pop(self):
+        self._drop_empty()
+        if not self._seg:
+            raise IndexError("pop from an empty SampleQueue")
+        g = self._seg[-1]
+        if _is_block(g):
+            g[2] -= 1
+            return LazySample(g[0], g[2])
+        return g.pop()
+
+    def popleft(self):
+        self._drop_empty()
+        if not self._seg:
+            raise IndexError("pop from an empty SampleQueue")
+        g = self._seg[0]
+        if _is_block(g):
+            g[1] += 1
+            return LazySample(g[0], g[1] - 1)
+        return g.pop(0)
+
+    def __iter__(self):
+        for g in list(self._seg):
+            if _is_block(g):
+                for i in range(g[1], g[2]):
+                    yield LazySample(g[0], i)
+            else:
+                yield from list(g)
+
+    def __getitem__(self, i):
+        n = len(self)
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(n))]
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("SampleQueue index out of range")
+        for g in self._seg:
+            m = g[2] - g[1] if _is_block(g) else len(g)
+            if i < m:
+                return LazySample(g[0], g[1] + i) if _is_block(g) else g[i]
+            i -= m
+        raise IndexError("SampleQueue index out of range")
+
+
+class _Block(list):
+    """[LazySamples, lo, hi]: a block segment of a SampleQueue (a list subclass so that it is told apart from a list of entries)"""
+
+
+def _is_block(g):
+    return type(g) is _Block
+
+
+class LazySample:
+    """One entry of LazySamples: unpacks, indexes and compares like the tuple (state, pi, z)."""
+    __slots__ = ("_blk", "_i")
+
+    def __init__(self, blk, i):
+        self._blk, self._i = blk, i
+
+    def _tuple(self):
+        b, i = self._blk, self._i
+        return (b.states()[i], b.pis[i], b.z[i])
+
+    def __iter__(self):
+        return iter(self._tuple())
+
+    def __getitem__(self, k):
+        return self._tuple()[k]
+
+    def __len__(self):
+        return 3
+
+
 def get_action(pi):
     """Sample the played move from np.random (utils.py:189-195). Returns (one-hot, index)."""
     n = len(pi)

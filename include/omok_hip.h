@@ -261,6 +261,14 @@ int  ao_replay_extend(ao_replay *r, const float *states, const double *pi, const
  * the memory (n * 8 >= capacity with augment), the earlier ones of the same call only move the ring position. */
 int  ao_replay_extend_skip(ao_replay *r, const float *states, const double *pi, const float *z, int64_t n,
                            int augment, int64_t skipped, void *stream);
+/* Device-side sample emission: the same append as ao_replay_extend_skip, but the states are BUILT ON THE DEVICE from the
+ * episodes' move lists instead of being uploaded -- replaces the per-ply utils.get_state_pt calls of main.py:159-166 /
+ * 219-227 (utils.py:139-168). moves int16 [n_episodes][max_len] (action indices in playing order, anything outside
+ * [0, board * board) is padding), sample i = the position of episode ep_of[i] after ply_of[i] of its moves (the root the
+ * search of that ply started from); pi / z / augment / skipped as above. */
+int  ao_replay_extend_moves(ao_replay *r, const int16_t *moves, int64_t n_episodes, int64_t max_len,
+                            const int32_t *ep_of, const int32_t *ply_of, const double *pi, const float *z,
+                            int64_t n, int augment, int64_t skipped, void *stream);
 /* Mini-batch for m deque indices (host int64; e.g. random.sample(range(len), m)): writes float32
  * device buffers states [m][C][B][B], pi [m][A], z [m] -- the tensors main.train feeds the net. */
 int  ao_replay_gather(ao_replay *r, const int64_t *idx, int64_t m, float *dev_states, float *dev_pi,

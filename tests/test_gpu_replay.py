@@ -96,6 +96,51 @@ def test_extend_augmented_arrays_uploads_only_what_survives(board, cap, n):
     mem.close()
 
 
+@pytest.mark.parametrize("board,C,cap,E", [(9, 17, 100000, 40), (15, 17, 5000, 12), (9, 5, 300, 30), (3, 5, 64, 6), (10, 3, 4096, 25),
+                                           (9, 1, 900, 7)])
+def test_states_built_on_the_device_from_move_lists(board, C, cap, E):
+    """ao_replay_extend_moves (device-side sample emission): the planes a kernel builds from the episodes' moves == the planes
+    of utils.get_state_pt (utils.py:139-168) uploaded through extend_augmented_arrays -- same ring contents, order and length,
+    also when the call alone overfills the memory (only the surviving samples are staged) and on top of older entries."""
+    from alpha_omok_amd import utils
+    from alpha_omok_amd.replay import DeviceReplay, ReplayError
+    rs = np.random.RandomState(board * 100 + C)
+    A = board * board
+    mem_d, mem_h = DeviceReplay(board, C, cap), DeviceReplay(board, C, cap)
+    for rnd in range(3):
+        lens = rs.randint(1, A + 1, E)
+        lens[0] = A                                        # a board played full
+        moves = np.full((E, A), -1, np.int32)
+        for e in range(E):
+            moves[e, :lens[e]] = rs.permutation(A)[:lens[e]]
+        ep_of = np.repeat(np.arange(E), lens)
+        ply_of = np.concatenate([np.arange(l) for l in lens])
+        if rnd == 1:                                       # samples need not be sorted, nor cover every ply
+            pick = rs.permutation(ep_of.size)[:max(1, ep_of.size // 3)]
+            ep_of, ply_of = ep_of[pick], ply_of[pick]
+        n = ep_of.size
+        pis = rs.dirichlet(np.ones(A), n)
+        z = rs.choice([-1.0, 0.0, 1.0], n)
+        states = utils.states_of_episodes(moves, ep_of, ply_of, board, C)
+        for i in rs.randint(0, n, 5):                      # the vectorised host builder against the per-sample restatement
+            node = (0,) + tuple(int(m) for m in moves[ep_of[i], :ply_of[i]])
+            np.testing.assert_array_equal(states[i], utils.get_state_pt(node, board, C))
+        mem_h.extend_augmented_arrays(states, pis, z)
+        mem_d.extend_augmented_moves(moves, ep_of, ply_of, pis, z)
+        assert len(mem_d) == len(mem_h) == min(cap, len(mem_h))
+        m = len(mem_h)
+        sd, pd, zd = mem_d.read(0, m)
+        sh, ph, zh = mem_h.read(0, m)
+        np.testing.assert_array_equal(sd, sh)
+        np.testing.assert_array_equal(pd, ph)
+        np.testing.assert_array_equal(zd, zh)
+    with pytest.raises(ReplayError):
+        mem_d.extend_augmented_moves(moves, np.array([E]), np.array([0]), pis[:1], z[:1])          # no such episode
+    with pytest.raises(ReplayError):
+        mem_d.extend_augmented_moves(moves, np.array([0]), np.array([A + 1]), pis[:1], z[:1])      # more plies than moves
+    mem_d.close(); mem_h.close()
+
+
 def test_batches_match_host_assembly():
     """batch(indices) == torch.tensor(np.stack(...)).float() of the same deque entries (main.py:283-290)."""
     import torch

@@ -500,3 +500,92 @@ def test_pad_state_dict_keeps_the_function():
             p0, v0 = m(x)
             p1, v1 = big(x)
         assert float((p0 - p1).abs().max()) < 1e-6 and float((v0 - v1).abs().max()) < 1e-6
+
+
+def test_lazy_samples_unpack_like_the_tuples_they_stand_for():
+    """main.self_play with rep_memory on the device appends utils.LazySamples to cur_memory: entries that count, unpack, index
+    and stack like (state, pi, z) of main.py:159-166, with the state rebuilt (get_state_pt, utils.py:139-168) on first access."""
+    from collections import deque
+    from alpha_omok_amd import utils
+    rs = np.random.RandomState(4)
+    B, C, E = 5, 7, 6
+    A = B * B
+    lens = rs.randint(1, A + 1, E)
+    moves = np.full((E, A), -1, np.int32)
+    for e in range(E):
+        moves[e, :lens[e]] = rs.permutation(A)[:lens[e]]
+    ep_of = np.repeat(np.arange(E), lens)
+    ply_of = np.concatenate([np.arange(l) for l in lens])
+    pis = rs.dirichlet(np.ones(A), ep_of.size)
+    z = rs.choice([-1.0, 0.0, 1.0], ep_of.size)
+    blk = utils.LazySamples(moves, ep_of, ply_of, pis, z, B, C)
+    mem = deque()
+    mem.extend(blk)
+    assert len(mem) == len(blk) == ep_of.size and blk._states is None        # counting builds nothing
+    mem.pop()
+    for i, (st, pi, zz) in enumerate(mem):
+        node = (0,) + tuple(int(m) for m in moves[ep_of[i], :ply_of[i]])
+        np.testing.assert_array_equal(st, utils.get_state_pt(node, B, C))
+        np.testing.assert_array_equal(pi, pis[i])
+        assert isinstance(zz, float) and zz == z[i]
+    e0 = mem[0]
+    assert len(e0) == 3 and e0[0].shape == (C, B, B) and e0[2] == z[0]
+    assert np.stack([b[0] for b in list(mem)[:4]]).shape == (4, C, B, B)     # main.train_batch's host assembly
+
+
+def test_sample_queue_behaves_like_the_deque_it_replaces():
+    """main.cur_memory is a utils.SampleQueue: the deque operations the reference and its users apply to cur_memory (main.py:56,
+    159-166, 229-231, 263, 374) on a mix of plain tuples and LazySamples blocks, compared with a real deque of the same entries."""
+    from collections import deque
+    from alpha_omok_amd import utils
+    import alpha_omok_amd.main as main
+    assert isinstance(main.cur_memory, utils.SampleQueue) and main.cur_memory.maxlen is None
+    rs = np.random.RandomState(9)
+    B, C = 4, 5
+    A = B * B
+
+    def block(E):
+        lens = rs.randint(1, A + 1, E)
+        moves = np.full((E, A), -1, np.int32)
+        for e in range(E):
+            moves[e, :lens[e]] = rs.permutation(A)[:lens[e]]
+        ep_of = np.repeat(np.arange(E), lens)
+        ply_of = np.concatenate([np.arange(l) for l in lens])
+        return utils.LazySamples(moves, ep_of, ply_of, rs.dirichlet(np.ones(A), ep_of.size), rs.choice([-1.0, 0.0, 1.0], ep_of.size), B, C)
+
+    def plain(n):
+        return [(rs.rand(C, B, B), rs.dirichlet(np.ones(A)), float(rs.choice([-1.0, 1.0]))) for _ in range(n)]
+
+    def same(q, d):
+        assert len(q) == len(d) and bool(q) == bool(d)
+        for i, (x, y) in enumerate(zip(q, d)):
+            for u, v in zip(x, y):
+                np.testing.assert_array_equal(u, v)
+            for u, v in zip(q[i], y):
+                np.testing.assert_array_equal(u, v)
+        if len(d):
+            np.testing.assert_array_equal(q[-1][1], d[-1][1])
+
+    q, d = utils.SampleQueue(), deque()
+    with pytest.raises(IndexError):
+        q.pop()
+    for step in range(3):
+        b1 = block(3)
+        q.extend(b1); d.extend(list(tuple(e) for e in b1))
+        p = plain(2)
+        q.extend(p); d.extend(p)
+        q.append(p[0]); d.append(p[0])
+        q.extend(utils.LazySamples(np.zeros((1, A), np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, A)), np.zeros(0), B, C))
+        same(q, d)
+        for _ in range(4):
+            x, y = q.pop(), d.pop()
+            np.testing.assert_array_equal(x[0], y[0]); assert x[2] == y[2]
+        for _ in range(2):
+            x, y = q.popleft(), d.popleft()
+            np.testing.assert_array_equal(x[0], y[0]); assert x[2] == y[2]
+        same(q, d)
+    assert len(q[2:5]) == 3
+    with pytest.raises(IndexError):
+        q[len(q)]
+    q.clear(); d.clear()
+    same(q, d)

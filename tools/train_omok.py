@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--eval-dense-until", type=int, default=0, help="evaluate after EVERY iteration up to this one (the steep part of the curve)")
     ap.add_argument("--ckpt-every", type=int, default=10)
     ap.add_argument("--max-ckpts", type=int, default=6, help="checkpoints kept on disk besides iteration 0 and final (gpurun_out is merged back up to 64 MiB)")
+    ap.add_argument("--host-states", action="store_true", help="build the samples' state planes on the host and upload them (main.DEVICE_STATES = False): the path before device-side sample emission")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--resume", default=None, help="state_dict to start from")
     a = ap.parse_args()
@@ -77,6 +78,7 @@ def main():
         print(json.dumps(rec), flush=True)
 
     m.BATCH_SIZE, m.LR, m.L2, m.MEMORY_SIZE, m.TRAIN_STEPS = a.batch, a.lr, a.l2, a.memory, a.steps
+    m.DEVICE_STATES = not a.host_states
     if a.rows_per_sim:
         m.MAX_CONCURRENT = a.rows_per_sim
     m.configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, out_planes=a.planes, seed=a.seed,
@@ -102,6 +104,7 @@ def main():
     t_end = time.time() + 60.0 * a.minutes
     games_total = moves_total = 0
     prev = dict(m.search_totals)
+    prev_phase = dict(m.phase_seconds)
     prev_model, prev_iter, chain = None, 0, 0.0
     it = 0
     while it < a.iters and time.time() < t_end:
@@ -112,6 +115,8 @@ def main():
         eng = m._engine
         d = {k: m.search_totals[k] - prev[k] for k in prev}   # this call's searches (main.search_totals is cumulative)
         prev = dict(m.search_totals)
+        ph = {k: round(m.phase_seconds[k] - prev_phase[k], 3) for k in prev_phase}   # searches / building + appending the samples
+        prev_phase = dict(m.phase_seconds)
         lengths = out["moves"] / max(out["episodes"], 1)
         res = dict(m.result)
         t0 = time.time()
@@ -126,7 +131,7 @@ def main():
         moves_total += out["moves"]
         ev, evg = eng.fp16_range_events()
         rec = dict(kind="iter", iter=it, games=out["episodes"], moves=out["moves"], self_play_s=round(t_sp, 2),
-                   moves_per_s=round(out["moves"] / t_sp, 1), mean_game_len=round(lengths, 2), result=res,
+                   moves_per_s=round(out["moves"] / t_sp, 1), self_play_phases_s=ph, mean_game_len=round(lengths, 2), result=res,
                    train_s=round(t_tr, 2), steps=len(losses), opt_step=m.step,
                    loss=[round(float(x), 4) for x in np.mean(np.array(losses), axis=0)] if losses else None,
                    mean_select_depth=round(d["levels"] / max(d["evaluated"] + d["terminal"], 1), 3),
