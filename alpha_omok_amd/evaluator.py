@@ -21,9 +21,12 @@ class Evaluator:
         self._net = None
         self._bufs = None
         self._warned_width = False
+        self._frozen = False   # freeze(): searches keep the weights exported last, whatever happens to the module (main.train_async)
         self.net_mode = 0      # ao_net_set_mode of the exported network (6: one kernel family for every batch size)
 
     def native_net(self, model, board_size, inplanes):
+        if self._frozen and self._net is not None:
+            return self._net
         cfg = pvnet.looks_like_pvnet(model)
         if cfg is not None and pvnet.native_width(cfg[2]) % 32 and cfg[3] == board_size and cfg[1] == inplanes:
             # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward covers up to 256 (other widths zero-padded to
@@ -59,6 +62,21 @@ class Evaluator:
             except TypeError:
                 self._ref = None
         return self._net
+
+    def freeze(self, model, board_size, inplanes):
+        """Export `model` now (if it changed) and keep searching with THAT copy until thaw(): the module's parameters may then be
+        updated in place by another thread (main.train_async) -- the native forward reads its own repacked weights in HBM, never the
+        module's tensors. False when the model has no native form (every simulation would call the module itself)."""
+        self._frozen = False
+        if self.native_net(model, board_size, inplanes) is None:
+            return False
+        self._frozen = True
+        return True
+
+    def thaw(self):
+        """End of freeze(): the next search re-exports the module's weights."""
+        self._frozen = False
+        self.invalidate()
 
     def invalidate(self):
         """Forget the exported weights: the next search re-exports Agent.model (called by main.train and

@@ -84,13 +84,19 @@ last_trace = []              # AO_SELFPLAY_TRACE=1: (active games, seconds) of e
 trim_stats = {'subtrees_dropped': 0, 'reroots_trimmed': 0}   # cumulative since configure(); also returned by self_play
 # search shape, cumulative since configure(): PUCT levels walked, exact-tie draws, terminal leaves, evaluated leaves over all
 # simulations of all searches (levels / (evaluated + terminal) = mean selection depth)
-phase_seconds = {'play': 0.0, 'emit': 0.0}   # cumulative since configure(): self_play's wall time inside the searches / building and appending the samples
+phase_seconds = {'play': 0.0, 'emit': 0.0, 'train_wait': 0.0}   # cumulative since configure(): self_play's wall time inside the searches / building and
+                             # appending the samples / waiting for an overlapped training pass (train_join) before the samples are appended
 search_totals = {'levels': 0, 'ties': 0, 'terminal': 0, 'evaluated': 0, 'searches': 0}
 CARRY_OVER = None            # configure(carry_over=True): slots freed at the end of one self_play call start the NEXT call's episodes
                              # (None = automatic: on inside run() when GAMES_PER_ITER is set, off otherwise)
 DEVICE_STATES = True         # with configure(device_replay=True): the samples' state planes are built on the device from the move lists
                              # (ao_replay_extend_moves) and cur_memory's entries rebuild theirs on first access; False = host-built
 CARRY_CALLS = 2              # ... of at most this many calls ahead
+OVERLAP_TRAIN = False        # configure(overlap_train=True): run() trains on a worker thread + side stream WHILE the next iteration's games are
+                             # played (train_async / train_join); 'serial' = the same deferred schedule without the thread (tests)
+_train_job = None            # the training pass in flight (train_async): dict(thread, plan, losses, error, wait_s)
+_train_stream = None
+last_train_losses = None     # losses of the pass train_join() finished last (self_play joins silently)
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
 _terminal_share = 0.0        # terminal leaves / simulations of the last search (drives ROWS = 'auto')
 _carry_auto = False          # run() with GAMES_PER_ITER set and CARRY_OVER None
@@ -98,7 +104,7 @@ _carry_auto = False          # run() with GAMES_PER_ITER set and CARRY_OVER None
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
               model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
-              carry_over=None, oversubscribe=None, rows=None):
+              carry_over=None, oversubscribe=None, rows=None, overlap_train=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
     node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 40 % of the HBM
     holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
@@ -116,9 +122,19 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     oversubscribe: game slots per row of the evaluation batch (MAX_CONCURRENT rows). 1.25 keeps 5120 games resident on 4096
     rows: the tree kernel hands out the rows per simulation, terminal leaves (11 - 19 % with a trained network) take none,
     and the extra games fill what they leave -- every game still runs the reference's strictly sequential search.
-    rows: 'static' / 'dynamic' / 'auto' (see ROWS)."""
+    rows: 'static' / 'dynamic' / 'auto' (see ROWS).
+    overlap_train=True: run() does not wait for an iteration's training pass -- it runs on a worker thread and a side stream while
+    the NEXT iteration's games are played with the weights exported before it started (train_async; the samples of those games are
+    appended, and the new weights published, after train_join). One iteration more of the asynchronous-actor trade carry_over
+    already makes; one process per GPU as before (the pass's collectives are issued by the worker thread only)."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
     global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP, CARRY_OVER, _pool, OVERSUBSCRIBE, ROWS, _terminal_share
+    global OVERLAP_TRAIN
+    train_join()
+    if overlap_train is not None:
+        if overlap_train not in (True, False, 'serial'):
+            raise ValueError("overlap_train must be True, False or 'serial'")
+        OVERLAP_TRAIN = overlap_train
     if carry_over is not None:
         CARRY_OVER = bool(carry_over)
     if oversubscribe is not None:
@@ -137,7 +153,7 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     trim_stats['subtrees_dropped'] = trim_stats['reroots_trimmed'] = 0
     for k in search_totals:
         search_totals[k] = 0
-    phase_seconds['play'] = phase_seconds['emit'] = 0.0
+    phase_seconds['play'] = phase_seconds['emit'] = phase_seconds['train_wait'] = 0.0
     import torch
     from .pvnet import PVNet
     BOARD_SIZE = board_size or BOARD_SIZE
@@ -506,6 +522,13 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
 
     t_emit = time.perf_counter()
     phase_seconds['play'] += t_emit - t_play
+    if _train_job is not None:
+        # an overlapped training pass (train_async) draws its mini-batches from rep_memory by position: it has to be over before this
+        # call's samples move the ring -- and its weights are published here, for the next call's searches
+        train_join()
+        t_join = time.perf_counter()
+        phase_seconds['train_wait'] += t_join - t_emit
+        t_emit = t_join
     # results and samples in episode order (main.py:201-227); samples arrive sorted by (episode, ply)
     result['Black'] += int((wins == 1).sum())
     result['White'] += int((wins == 2).sum())
@@ -603,9 +626,14 @@ def train(n_epochs, n_iter):
     everywhere. A rank whose shard is too small for a step (or empty) adds zeros and is left out of
     the divisor, so every rank issues exactly the same collectives and the weights stay bit-identical
     across ranks; the BatchNorm running statistics are averaged once at the end of the pass."""
-    global total_epoch
+    train_join()
+    return _train_execute(_train_plan(), n_epochs)
+
+
+def _train_plan():
+    """What a training pass needs from the CALLING thread: the number of mini-batches, the positions random.sample picks (the
+    `random` stream is consumed here) and, under torch.distributed, the per-step sample totals all ranks agree on."""
     rank, world = parallel.world()
-    Agent.model.train()
     on_device = hasattr(rep_memory, "batch")
     if world == 1:
         n_steps = len(cur_memory) if TRAIN_STEPS is None else int(TRAIN_STEPS)
@@ -619,13 +647,22 @@ def train(n_epochs, n_iter):
     logging.warning('current memory size: {}'.format(len(cur_memory)))
     logging.warning('replay memory size: {}'.format(len(rep_memory)))
     logging.warning('train memory size: {}'.format(len(train_memory)))
-    losses = []
-    trained = False
     # the samples all ranks together put behind each mini-batch of the pass: one small all-reduce here instead of a
     # device read-back inside every gradient all-reduce
     totals = [None] * n_steps
     if world > 1:
         totals = parallel.agree_sums([len(train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]) for i in range(n_steps)], device)
+    return n_steps, train_memory, totals
+
+
+def _train_execute(plan, n_epochs, publish=True):
+    """The mini-batches of a planned pass (main.py:266-336). publish=False (train_async's worker): the searches' native copy of the
+    weights is NOT invalidated here -- train_join does that on the thread that runs the searches."""
+    global total_epoch
+    n_steps, train_memory, totals = plan
+    Agent.model.train()
+    losses = []
+    trained = False
     for epoch in range(n_epochs):
         for i in range(n_steps):
             batch = train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]
@@ -640,9 +677,72 @@ def train(n_epochs, n_iter):
             m = np.mean(np.array(losses), axis=0)
             logging.warning('{:2} Epoch Loss: {:.4f}   Loss_V: {:.4f}   Loss_P: {:.4f}'.format(total_epoch, *m))
     parallel.average_buffers(Agent.model, contributes=trained)
-    if _evaluator is not None:
+    if publish and _evaluator is not None:
         _evaluator.invalidate()                           # the native copy of the weights is stale now
     return losses
+
+
+def train_async(n_epochs, n_iter):
+    """train() that does not make the GPU's games wait (round-4 review, item 4b; the loop it serves: main.py:377-414). The pass is
+    planned here, on the calling thread (sampling, agreement across ranks); its mini-batches then run on a worker thread and a
+    side stream while the caller goes on to the next self_play call. Until train_join() the searches keep the weights exported
+    BEFORE the pass started (Evaluator.freeze: the native forward reads its own repacked copy in HBM, so the module can be
+    updated in place next to it); self_play calls train_join() itself before it appends its samples -- the pass draws from
+    rep_memory by position -- and so do train / save_model / save_dataset / load_data / configure. A model without a native
+    form (its module would be called by the searches while it is being trained) gets the plain synchronous pass.
+    OVERLAP_TRAIN = 'serial' keeps the schedule and drops the thread: the pass runs inside train_join (tests)."""
+    global _train_job, _train_stream
+    train_join()
+    if _evaluator is None or not device.type == 'cuda' or not _evaluator.freeze(Agent.model, BOARD_SIZE, IN_PLANES):
+        losses = _train_execute(_train_plan(), n_epochs)
+        _train_job = dict(thread=None, losses=losses, error=None, done=True)
+        return
+    plan = _train_plan()
+    job = dict(thread=None, plan=plan, n_epochs=n_epochs, losses=None, error=None, done=False)
+    if OVERLAP_TRAIN == 'serial':
+        _train_job = job
+        return
+    import threading
+    import torch
+    torch.cuda.synchronize(device)                        # everything the pass reads (the replay ring's last append) is in memory
+    if _train_stream is None or _train_stream.device != device:
+        _train_stream = torch.cuda.Stream(device)         # (torch's pool streams do not synchronise with the null stream)
+
+    def work():
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(_train_stream):
+                job['losses'] = _train_execute(plan, n_epochs, publish=False)
+            _train_stream.synchronize()
+        except BaseException as e:                        # handed to the thread that joins
+            job['error'] = e
+        job['done'] = True
+
+    job['thread'] = threading.Thread(target=work, name="alpha_omok_amd.train", daemon=True)
+    _train_job = job
+    job['thread'].start()
+
+
+def train_join():
+    """Wait for the pass train_async started, publish its weights to the searches, return its losses (None: nothing was in
+    flight). Raises what the pass raised."""
+    global _train_job, last_train_losses
+    job = _train_job
+    if job is None:
+        return None
+    _train_job = None
+    try:
+        if job['thread'] is not None:
+            job['thread'].join()
+        elif not job['done']:
+            job['losses'] = _train_execute(job['plan'], job['n_epochs'], publish=False)
+    finally:
+        if _evaluator is not None:
+            _evaluator.thaw()
+    if job['error'] is not None:
+        raise job['error']
+    last_train_losses = job['losses']
+    return job['losses']
 
 
 def reset_iter(result_, cur_memory_):
@@ -658,6 +758,7 @@ def reset_iter(result_, cur_memory_):
 # ---- checkpoint wire format (main.py:339-365): torch.save(state_dict) / pickled rep_memory, with the
 # iteration and step encoded in the file name and parsed back on load ----
 def save_model(agent, n_iter, step_, directory='data', datetime_now=None):
+    train_join()
     import os
     from datetime import datetime
     import torch
@@ -669,6 +770,7 @@ def save_model(agent, n_iter, step_, directory='data', datetime_now=None):
 
 
 def save_dataset(memory, n_iter, step_, directory='data', datetime_now=None):
+    train_join()
     import os
     import pickle
     from datetime import datetime
@@ -694,6 +796,7 @@ def load_data(model_path, dataset_path):
     import os
     import pickle
     import torch
+    train_join()
     if model_path:
         state = Agent.model.state_dict()
         state.update(torch.load(model_path, map_location=device))
@@ -773,16 +876,21 @@ def run(total_iter=None, model_path=None, dataset_path=None, n_selfplay=None, sa
                 self_play(parallel.world()[1] if GAMES_PER_ITER is None else int(GAMES_PER_ITER))
             finally:
                 _carry_auto = False
-            train(N_EPOCHS, n_iter)
+            if OVERLAP_TRAIN:
+                train_async(N_EPOCHS, n_iter)             # joined by the next self_play before it appends its samples (or below)
+            else:
+                train(N_EPOCHS, n_iter)
         else:
             self_play(n_first)
         if n_iter % save_every == 0:
+            train_join()                                  # a checkpoint holds the weights AFTER this iteration's pass, as in the reference
             today = parallel.agree(int(datetime.now().strftime('%y%m%d')), "max", device)   # one file-name date for all ranks
             if parallel.world()[0] == 0:
                 save_model(Agent, n_iter + save_every, step, directory, '{:06d}'.format(today))
             save_dataset(rep_memory, n_iter + save_every, step, directory, '{:06d}'.format(today))   # every rank: its own shard
         reset_iter(result, cur_memory)
         done += 1
+    train_join()
     return done
 
 

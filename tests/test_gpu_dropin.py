@@ -287,6 +287,79 @@ def test_over_subscribed_self_play_plays_the_same_episodes():
     main.release_engine()
 
 
+def test_overlapped_training_keeps_the_searches_on_the_weights_exported_before_it():
+    """main.train_async (configure(overlap_train=True); the loop: main.py:377-414): the pass runs on a worker thread and a side stream
+    while the next self_play call is being played. That call's searches must see the weights exported BEFORE the pass -- its samples
+    equal the samples of a run that never trains --, the pass must be the one a serial execution of the same schedule makes
+    (overlap_train='serial': same plan, executed inside train_join), the samples are appended after the join, and the call after
+    that plays with the NEW weights."""
+    import threading
+    import torch
+    import alpha_omok_amd.main as main
+    B, S, N = 9, 16, 24
+
+    def run(mode):
+        torch.manual_seed(5)
+        import random
+        main.MAX_CONCURRENT = 32
+        main.configure(board_size=B, n_mcts=S, n_blocks=1, in_planes=5, out_planes=32, seed=40, reproducible=True, device_replay=True,
+                       overlap_train=mode if mode != 'none' else False)
+        main.TRAIN_STEPS, main.BATCH_SIZE = 12, 32
+        main.result.update(Black=0, White=0, Draw=0)
+        main.rep_memory.clear(); main.cur_memory.clear()
+        main.step = 0
+        random.seed(9)
+        out = {}
+        main.self_play(N)
+        main.reset_iter(main.result, main.cur_memory)
+        if mode != 'none':
+            main.train_async(1, 1)
+            out['threaded'] = main._train_job['thread'] is not None
+            out['frozen'] = main._evaluator._frozen
+        n_rep = len(main.rep_memory)
+        main.self_play(N)                                  # (joins the pass before it appends)
+        out['joined'] = main._train_job is None and not main._evaluator._frozen
+        out['call1'] = [(s.copy(), p.copy(), z) for s, p, z in main.cur_memory]
+        out['appended'] = len(main.rep_memory) - n_rep
+        out['losses'] = main.last_train_losses
+        out['step'] = main.step
+        out['weights'] = {k: v.detach().cpu().clone() for k, v in main.Agent.model.state_dict().items()}
+        main.reset_iter(main.result, main.cur_memory)
+        main.self_play(8)
+        out['call2'] = [(s.copy(), p.copy(), z) for s, p, z in main.cur_memory]
+        main.reset_iter(main.result, main.cur_memory)
+        return out
+
+    try:
+        none, serial, thread = run('none'), run('serial'), run(True)
+        assert thread['threaded'] and not serial['threaded'] and thread['frozen'] and serial['frozen']
+        assert thread['joined'] and serial['joined']
+        assert not any(t.name == "alpha_omok_amd.train" for t in threading.enumerate())
+        assert none['step'] == 0 and serial['step'] == 12 and thread['step'] == 12
+        assert thread['appended'] == serial['appended'] == none['appended'] == 8 * len(none['call1'])
+        # the call played beside the pass = the call of a run that never trained, sample for sample
+        for other in (serial, thread):
+            assert len(other['call1']) == len(none['call1'])
+            for (s0, p0, z0), (s1, p1, z1) in zip(none['call1'], other['call1']):
+                assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
+        # the pass itself: same mini-batches from the same weights, next to a running search or alone
+        assert len(thread['losses']) == len(serial['losses']) == 12
+        np.testing.assert_allclose(np.array(thread['losses']), np.array(serial['losses']), rtol=0, atol=1e-5)
+        for k, v in serial['weights'].items():
+            if v.dtype.is_floating_point:
+                np.testing.assert_allclose(thread['weights'][k].numpy(), v.numpy(), rtol=0, atol=1e-5, err_msg=k)
+        moved = max(float((serial['weights'][k] - none['weights'][k]).abs().max()) for k in none['weights']
+                    if serial['weights'][k].dtype.is_floating_point)
+        assert moved > 1e-4                                 # (it did train)
+        # ... and the call after the join plays with the new weights
+        same = len(none['call2']) == len(thread['call2']) and all(np.array_equal(a[1], b[1]) for a, b in zip(none['call2'], thread['call2']))
+        assert not same
+    finally:
+        main.TRAIN_STEPS, main.BATCH_SIZE, main.MAX_CONCURRENT = None, 32, 4096
+        main.configure(board_size=B, n_mcts=S, n_blocks=2, out_planes=128, seed=0, reproducible=False, overlap_train=False)
+        main.release_engine()
+
+
 def test_self_play_reports_arena_trims_and_strict_mode_raises(oracle):
     """A tree arena too small for what the searches keep from move to move makes re-rooting forget subtrees -- a
     divergence from the reference's never-pruned dict (agents.py:52) that must not pass silently: self_play returns /

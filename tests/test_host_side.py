@@ -589,3 +589,96 @@ def test_sample_queue_behaves_like_the_deque_it_replaces():
         q[len(q)]
     q.clear(); d.clear()
     same(q, d)
+
+
+def test_overlapped_training_schedule_and_host_logic(monkeypatch):
+    """configure(overlap_train=True): run() hands an iteration's training pass to train_async and only waits for it where somebody
+    needs its result (the next self_play before it appends samples, a checkpoint, the end of run). Here: the call order of the
+    loop, the synchronous fallback where the searches would have to call the module that is being trained (no GPU: no native
+    export), train_join's bookkeeping, and 'serial' mode (same schedule, the pass runs inside train_join). main.py:377-414."""
+    import random
+    from alpha_omok_amd import main
+    from alpha_omok_amd.evaluator import Evaluator
+    calls = []
+    monkeypatch.setattr(main, "Agent", object())
+    monkeypatch.setattr(main, "self_play", lambda n: calls.append(("play", n)))
+    monkeypatch.setattr(main, "train", lambda e, i: calls.append(("train", i)))
+    monkeypatch.setattr(main, "train_async", lambda e, i: calls.append(("train_async", i)))
+    monkeypatch.setattr(main, "train_join", lambda: calls.append(("join",)))
+    monkeypatch.setattr(main, "load_data", lambda a, b: None)
+    monkeypatch.setattr(main, "save_model", lambda *a, **k: calls.append(("save",)))
+    monkeypatch.setattr(main, "save_dataset", lambda *a, **k: None)
+    monkeypatch.setattr(main, "start_iter", 0)
+    monkeypatch.setattr(main, "GAMES_PER_ITER", None)
+    monkeypatch.setattr(main, "OVERLAP_TRAIN", True)
+    assert main.run(total_iter=4, n_selfplay=7, save_every=2) == 4
+    assert calls == [("play", 7), ("join",), ("save",), ("play", 1), ("train_async", 1), ("play", 1), ("train_async", 2), ("join",), ("save",),
+                     ("play", 1), ("train_async", 3), ("join",)]
+    monkeypatch.undo()
+
+    with pytest.raises(ValueError):
+        main.configure(board_size=3, n_mcts=4, n_blocks=1, out_planes=32, seed=1, gpu=0, overlap_train="yes")
+    main.configure(board_size=3, n_mcts=4, n_blocks=1, out_planes=32, seed=1, gpu=0, overlap_train=True)
+    try:
+        assert main.OVERLAP_TRAIN is True and main.train_join() is None
+        rs = np.random.RandomState(0)
+        main.rep_memory.clear(); main.cur_memory.clear()
+        for _ in range(200):
+            pi = rs.rand(9); pi /= pi.sum()
+            main.rep_memory.append(((rs.rand(5, 3, 3) < 0.3).astype(np.float64), pi, float(rs.choice([-1.0, 0.0, 1.0]))))
+        main.cur_memory.extend(list(main.rep_memory)[:3])
+        main.TRAIN_STEPS, main.BATCH_SIZE = 4, 16
+        import copy
+        import torch
+        w0 = copy.deepcopy(main.Agent.model.state_dict())
+        opt0 = copy.deepcopy(main.optimizer.state_dict())
+        random.seed(4); torch.manual_seed(4); main.step = 0
+        ref = main.train(1, 1)
+        w_ref = copy.deepcopy(main.Agent.model.state_dict())
+        # no GPU here: nothing native to freeze -> the pass runs at once, on this thread, and train_join only hands the losses over
+        main.Agent.model.load_state_dict(w0); main.optimizer.load_state_dict(opt0)
+        random.seed(4); torch.manual_seed(4); main.step = 0
+        main.train_async(1, 1)
+        assert main.step == 4 and main._train_job is not None and main._train_job['thread'] is None
+        got = main.train_join()
+        assert main._train_job is None and main.train_join() is None and main.last_train_losses == got
+        np.testing.assert_array_equal(np.array(got), np.array(ref))
+        for k, v in main.Agent.model.state_dict().items():
+            assert torch.equal(v, w_ref[k]), k
+
+        # Evaluator.freeze / thaw: a frozen evaluator hands out the copy exported last without looking at the module
+        ev = Evaluator(0)
+        sentinel = object()
+        ev._net = sentinel
+        ev._frozen = True
+        assert ev.native_net(main.Agent.model, 3, 5) is sentinel
+        ev._net = None                                  # (nothing exported: freeze() reports that it cannot, and stays thawed)
+        assert ev.freeze(object(), 3, 5) is False and ev._frozen is False
+        ev._key = ("x",)
+        ev.thaw()
+        assert ev._frozen is False and ev._key is None
+
+        # 'serial': the pass is planned by train_async (the `random` stream moves there) and executed inside train_join
+        class FakeEval:
+            frozen = thawed = 0
+            def freeze(self, *a): FakeEval.frozen += 1; return True
+            def thaw(self): FakeEval.thawed += 1
+            def invalidate(self): pass
+        monkeypatch.setattr(main, "_evaluator", FakeEval())
+        monkeypatch.setattr(main, "device", type("D", (), {"type": "cuda"})())
+        monkeypatch.setattr(main, "OVERLAP_TRAIN", "serial")
+        main.Agent.model.load_state_dict(w0); main.optimizer.load_state_dict(opt0)
+        random.seed(4); torch.manual_seed(4); main.step = 0
+        state_before = random.getstate()
+        main.train_async(1, 1)
+        assert main.step == 0 and FakeEval.frozen == 1 and random.getstate() != state_before
+        monkeypatch.undo()                              # (the real device again for the pass itself)
+        monkeypatch.setattr(main, "_evaluator", FakeEval())
+        got = main.train_join()
+        assert main.step == 4 and FakeEval.thawed == 1
+        np.testing.assert_array_equal(np.array(got), np.array(ref))
+    finally:
+        monkeypatch.undo()
+        main._train_job = None
+        main.TRAIN_STEPS, main.BATCH_SIZE, main.OVERLAP_TRAIN = None, 32, False
+        main.rep_memory.clear(); main.cur_memory.clear()

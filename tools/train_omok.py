@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--ckpt-every", type=int, default=10)
     ap.add_argument("--max-ckpts", type=int, default=6, help="checkpoints kept on disk besides iteration 0 and final (gpurun_out is merged back up to 64 MiB)")
     ap.add_argument("--host-states", action="store_true", help="build the samples' state planes on the host and upload them (main.DEVICE_STATES = False): the path before device-side sample emission")
+    ap.add_argument("--overlap-train", action="store_true",
+                    help="main.train_async: an iteration's training pass runs on a worker thread and a side stream while the NEXT iteration's "
+                         "games are played with the weights exported before it started (one more iteration of staleness than carry-over already has)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--resume", default=None, help="state_dict to start from")
     a = ap.parse_args()
@@ -121,7 +124,18 @@ def main():
         res = dict(m.result)
         t0 = time.time()
         try:
-            losses = m.train(m.N_EPOCHS, it)
+            if a.overlap_train:
+                # the PREVIOUS iteration's pass was joined inside self_play (phase 'train_wait'); this one runs beside the next call
+                # (so the `loss` of a line is the loss of the pass that ENDED during this iteration: one iteration behind)
+                losses = m.last_train_losses or []
+                m.last_train_losses = None
+                m.train_async(m.N_EPOCHS, it)
+                last_iter = it + 1 >= a.iters or time.time() >= t_end
+                evaluating = (it + 1) % a.eval_every == 0 or it + 1 <= a.eval_dense_until or (it + 1) % a.ckpt_every == 0
+                if last_iter or evaluating:               # whoever reads Agent.model needs the pass finished
+                    m.train_join()
+            else:
+                losses = m.train(m.N_EPOCHS, it)
         except ValueError as e:                           # replay still smaller than BATCH_SIZE x TRAIN_STEPS
             losses = []
             emit(dict(kind="note", iter=it, msg="train skipped: %s" % e))
@@ -186,6 +200,7 @@ def main():
             kept.append(path)
             while len(kept) > a.max_ckpts:                # thin out: drop the second-oldest, keep the spread
                 os.remove(kept.pop(1 if len(kept) > 2 else 0))
+    m.train_join()
     torch.save(m.Agent.model.state_dict(), os.path.join(a.out, "final.pt"))
     emit(dict(kind="done", iters=it, games_total=games_total, moves_total=moves_total))
 
