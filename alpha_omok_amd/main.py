@@ -473,8 +473,9 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
     global _episodes_played, _pool
     if Agent is None:
         configure()
-    if hasattr(Agent.model, "eval"):
-        Agent.model.eval()
+    if hasattr(Agent.model, "eval") and _train_job is None:
+        Agent.model.eval()                                # (main.py:124; not while an overlapped pass is training this module: the
+                                                          # searches run on the exported copy, and the join below sets the mode)
     rank, world = parallel.world()
     if single_stream and world > 1:
         raise ValueError("single_stream self-play is the reference's sequential schedule: one process only")
@@ -526,6 +527,8 @@ def self_play(n_selfplay, seeds=None, single_stream=False):
         # an overlapped training pass (train_async) draws its mini-batches from rep_memory by position: it has to be over before this
         # call's samples move the ring -- and its weights are published here, for the next call's searches
         train_join()
+        if hasattr(Agent.model, "eval"):
+            Agent.model.eval()
         t_join = time.perf_counter()
         phase_seconds['train_wait'] += t_join - t_emit
         t_emit = t_join
