@@ -124,25 +124,35 @@ def test_two_ranks_with_carry_over_return_their_shards_of_every_call(tmp_path):
                     assert np.array_equal(s0, s1) and np.array_equal(p0, p1) and z0 == z1
 
 
-def _run_worker(rank, world, port, out, tmp):
+def _run_worker(rank, world, port, out, tmp, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import random
     from alpha_omok_amd import main, parallel
     parallel.init_from_env("gloo")
     torch.manual_seed(100 + rank)                      # configure() must broadcast rank 0's weights
-    main.configure(board_size=B, n_mcts=8, n_blocks=1, out_planes=32, seed=3, gpu=0)
+    main.configure(board_size=B, n_mcts=8, n_blocks=1, out_planes=32, seed=3, gpu=0, overlap_train=overlap)
     random.seed(300 + rank)                            # rank-local replay draws
     main.rep_memory.clear(); main.cur_memory.clear()
     main.step = 0; main.start_iter = 0
     lens = []
-    orig_train = main.train
-    def spy(n_epochs, n_iter):
+    orig_plan = main._train_plan
+    def spy():                                         # (train and train_async both plan their pass here, on the calling thread)
         lens.append(len(main.cur_memory))
-        return orig_train(n_epochs, n_iter)
-    main.train = spy
-    n = main.run(total_iter=3, n_selfplay=7, save_every=2, directory=tmp)
-    main.train = orig_train
+        return orig_plan()
+    main._train_plan = spy
+    threads = []
+    if overlap:
+        orig_async = main.train_async
+        def spy_async(n_epochs, n_iter):
+            orig_async(n_epochs, n_iter)
+            threads.append(main._train_job['thread'] is not None)
+        main.train_async = spy_async
+    n = main.run(total_iter=4 if overlap else 3, n_selfplay=7, save_every=2, directory=tmp)
+    main._train_plan = orig_plan
+    if overlap:
+        main.train_async = orig_async
+        assert threads == [True] * 3 and main._train_job is None, threads
     sd = {k: v.detach().cpu().clone() for k, v in main.Agent.model.state_dict().items()}
     torch.save(dict(n=n, step=main.step, sd=sd, lens=lens, rep=len(main.rep_memory)), out % rank)
     import torch.distributed as dist
@@ -170,6 +180,28 @@ def test_two_ranks_run_the_training_loop_without_deadlock(tmp_path):
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     models = [f for f in os.listdir(ck) if f.endswith("_step_model.pickle")]
     assert len(models) == 2                               # n_iter 0 and 2, written once (rank 0)
+
+
+def test_two_ranks_run_the_overlapped_training_loop(tmp_path):
+    """The same loop with configure(overlap_train=True): every pass is planned on the main thread (the agreement collectives), its
+    gradient all-reduces are issued by the worker thread while the main thread plays the next iteration's games (no collective
+    there), joined before the next plan / checkpoint -- every rank issues the same collectives in the same order: no deadlock,
+    the same number of optimiser steps everywhere, bit-identical weights and BatchNorm buffers across ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "run%d.pt")
+    ck = tmp_path / "ck"
+    mp.spawn(_run_worker, args=(2, port, out, str(ck), True), nprocs=2, join=True)
+    r0, r1 = (torch.load(out % r, weights_only=False) for r in range(2))
+    assert r0["n"] == r1["n"] == 4
+    assert len(r0["lens"]) == len(r1["lens"]) == 3
+    want_steps = sum(-(-(a + b) // 2) for a, b in zip(r0["lens"], r1["lens"]))
+    assert r0["step"] == r1["step"] == want_steps > 0
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    models = [f for f in os.listdir(ck) if f.endswith("_step_model.pickle")]
+    assert len(models) == 2                               # n_iter 0 and 2 (its pass joined first), written once (rank 0)
 
 
 def _rccl_worker(rank, world, port, out):
