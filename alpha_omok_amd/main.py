@@ -94,6 +94,7 @@ DEVICE_STATES = True         # with configure(device_replay=True): the samples' 
 CARRY_CALLS = 2              # ... of at most this many calls ahead
 OVERLAP_TRAIN = False        # configure(overlap_train=True): run() trains on a worker thread + side stream WHILE the next iteration's games are
                              # played (train_async / train_join); 'serial' = the same deferred schedule without the thread (tests)
+played_ahead = [0]           # carry-over + overlapped training: searches made for LATER calls' games while a call that was complete waited for the pass
 _train_job = None            # the training pass in flight (train_async): dict(thread, plan, losses, error, wait_s)
 _train_stream = None
 last_train_losses = None     # losses of the pass train_join() finished last (self_play joins silently)
@@ -416,7 +417,16 @@ def _play_carry(first_episode, n_call, rank, world):
 
     start(np.flatnonzero(pool.active == 0))
     trace = [] if os.environ.get("AO_SELFPLAY_TRACE") else None
-    while todo:
+
+    def pass_running():
+        # an overlapped training pass (train_async) that is still at work: self_play would only wait for it (train_join, before
+        # the samples are appended) -- the games of the calls to come are played on in the meantime, under the same frozen weights
+        job = _train_job
+        return job is not None and job['thread'] is not None and job['thread'].is_alive()
+
+    while todo or (pass_running() and pool.active.any()):
+        if not todo:
+            played_ahead[0] += 1
         if not pool.active.any():
             raise RuntimeError("carry-over self-play: episodes %r are neither in flight nor finished" % sorted(todo)[:8])
         tau = (pool.ply < TAU_THRES).astype(np.int8)      # main.py:150-153
@@ -700,7 +710,11 @@ def train_async(n_epochs, n_iter):
         losses = _train_execute(_train_plan(), n_epochs)
         _train_job = dict(thread=None, losses=losses, error=None, done=True)
         return
-    plan = _train_plan()
+    try:
+        plan = _train_plan()
+    except BaseException:                                 # (e.g. the reference's ValueError for a replay memory that is too small)
+        _evaluator.thaw()
+        raise
     job = dict(thread=None, plan=plan, n_epochs=n_epochs, losses=None, error=None, done=False)
     if OVERLAP_TRAIN == 'serial':
         _train_job = job

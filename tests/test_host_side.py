@@ -677,6 +677,14 @@ def test_overlapped_training_schedule_and_host_logic(monkeypatch):
         got = main.train_join()
         assert main.step == 4 and FakeEval.thawed == 1
         np.testing.assert_array_equal(np.array(got), np.array(ref))
+        # a pass that cannot be planned (the reference's ValueError, main.py:263-264) leaves nothing frozen and nothing in flight
+        monkeypatch.setattr(main, "device", type("D", (), {"type": "cuda"})())
+        monkeypatch.setattr(main, "OVERLAP_TRAIN", "serial")
+        main.TRAIN_STEPS = 1000
+        with pytest.raises(ValueError):
+            main.train_async(1, 1)
+        assert FakeEval.frozen == 2 and FakeEval.thawed == 2 and main._train_job is None
+        main.TRAIN_STEPS = 4
     finally:
         monkeypatch.undo()
         main._train_job = None
