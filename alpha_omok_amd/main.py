@@ -922,7 +922,13 @@ if __name__ == '__main__':
     ap.add_argument('--model', default=None)
     ap.add_argument('--dataset', default=None)
     ap.add_argument('--device-replay', action='store_true')
+    ap.add_argument('--games-per-iter', type=int, default=None, help='games of every iteration after the first (default: the reference\'s one game per rank)')
+    ap.add_argument('--train-steps', type=int, default=None, help='mini-batches per training pass (default: the reference\'s one per new sample)')
+    ap.add_argument('--oversubscribe', type=float, default=None, help='game slots per row of the evaluation batch (1.25 with a trained network)')
+    ap.add_argument('--overlap-train', action='store_true', help='train beside the next iteration\'s games (train_async)')
     a = ap.parse_args()
     parallel.init_from_env()
-    configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, device_replay=a.device_replay)
+    GAMES_PER_ITER, TRAIN_STEPS = a.games_per_iter, a.train_steps
+    configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, device_replay=a.device_replay, oversubscribe=a.oversubscribe,
+              overlap_train=a.overlap_train)
     run(a.iters, a.model, a.dataset, a.selfplay)
