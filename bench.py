@@ -276,6 +276,19 @@ def match_traffic(tj, kname, csrc_sha, workload_is_default):
     return tj.get("hbm_bytes_per_launch"), tree, None
 
 
+def other_workload_traffic(tj, csrc_sha, board, games, blocks, planes, kname):
+    """HBM bytes per launch from the profile's `other_workloads` -- records of other workloads collected from the SAME kernel
+    sources (e.g. the configs[4] per-GPU shape) -- or None."""
+    if not tj or tj.get("csrc_sha16") != csrc_sha:
+        return None
+    for w in tj.get("other_workloads", []):
+        wl = w.get("workload", {})
+        if ((wl.get("board"), wl.get("games"), wl.get("blocks"), wl.get("planes")) == (board, games, blocks, planes)
+                and kernel_key(w.get("kernel", "")) == kernel_key(kname)):
+            return w.get("hbm_bytes_per_launch")
+    return None
+
+
 def newest_traffic_profile():
     import glob
     import re
@@ -670,6 +683,7 @@ def main():
         traffic = None
         traffic_src = None
         tree_traffic = None
+        tj = None
         traffic_why = "no profile"
         from alpha_omok_amd.build import source_hash
         csrc_sha = source_hash()
@@ -679,14 +693,10 @@ def main():
                 tj = json.load(f)
             same_load = (G == 4096 and B == 9 and args.blocks == 4 and args.planes == 128 and S == 400)
             traffic, tree_traffic, traffic_why = match_traffic(tj, kname, csrc_sha, same_load)
-            if traffic is None and not same_load and tj.get("csrc_sha16") == csrc_sha:
-                # the profile may carry records of other workloads collected in the same session (e.g. the configs[4] per-GPU shape)
-                for w in tj.get("other_workloads", []):
-                    wl = w.get("workload", {})
-                    if ((wl.get("board"), wl.get("games"), wl.get("blocks"), wl.get("planes")) == (B, G, args.blocks, args.planes)
-                            and kernel_key(w.get("kernel", "")) == kernel_key(kname)):
-                        traffic, traffic_why = w.get("hbm_bytes_per_launch"), None
-                        break
+            if traffic is None and not same_load:
+                t2 = other_workload_traffic(tj, csrc_sha, B, G, args.blocks, args.planes, kname)
+                if t2 is not None:
+                    traffic, traffic_why = t2, None
         except Exception as e:
             traffic, traffic_why = None, "profile unreadable: %r" % (e,)
         sims_total = max(counters["evaluated"] + counters["terminal"], 1)
@@ -853,7 +863,8 @@ def main():
                                      "flops_per_move_algorithmic": Sw * eval_flops(Bw, 5, args.planes, 10),
                                      "roofline": {"bound": "mfma", "kernel": kw.split(" (")[0], "flop_per_launch": fw, "avg_launch_ms": aw, "launches_timed": cw_n,
                                                   "achieved": fw / (aw * 1e-3) / 1e12 if cw_n else 0.0, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                                  "frac": fw / (aw * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if cw_n else 0.0}}
+                                                  "frac": fw / (aw * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if cw_n else 0.0,
+                                                  "traffic": other_workload_traffic(tj, csrc_sha, Bw, Gw, 10, args.planes, kw)}}
                 engw.close()
                 netw.close()
             except Exception as e:

@@ -120,3 +120,17 @@ def test_build_lists_cover_every_source_and_header_under_csrc():
     finally:
         builtins.open = real_open
     assert h1 != h0, "source_hash() does not cover net_layer_ksplit.hpp"
+
+
+def test_other_workload_traffic_is_keyed_on_sources_shape_and_kernel():
+    """bench.other_workload_traffic: the configs[4]-shape record of a traffic profile is used for the `wide_board` leg / a --board 15
+    run only when it was collected from the same kernel sources, for that shape, on that kernel."""
+    import bench
+    tj = {"csrc_sha16": "abc", "other_workloads": [{"kernel": "k_boardh<15, 2>", "hbm_bytes_per_launch": 7.0e8,
+                                                    "workload": {"board": 15, "games": 1024, "blocks": 10, "planes": 128}}]}
+    assert bench.other_workload_traffic(tj, "abc", 15, 1024, 10, 128, "k_boardh<15, 2> (conv1 + 20 convs ...)") == 7.0e8
+    assert bench.other_workload_traffic(tj, "abd", 15, 1024, 10, 128, "k_boardh<15, 2>") is None      # other sources
+    assert bench.other_workload_traffic(tj, "abc", 15, 2048, 10, 128, "k_boardh<15, 2>") is None      # other shape
+    assert bench.other_workload_traffic(tj, "abc", 15, 1024, 10, 128, "k_layer16h<15>") is None       # other kernel
+    assert bench.other_workload_traffic(None, "abc", 15, 1024, 10, 128, "k_boardh<15, 2>") is None
+    assert bench.other_workload_traffic({"csrc_sha16": "abc"}, "abc", 15, 1024, 10, 128, "k_boardh<15, 2>") is None
