@@ -15,7 +15,7 @@ for l in sys.stdin:
             tag, d["iter"], d["games"], d["self_play_s"], ph["play"], ph.get("train_wait", 0.0), d["train_s"], d["loss"], mv / sp, mv / (sp + tr)))
 '
 for tag in S O; do
-  extra=""; [ $tag = O ] && extra="--overlap-train"
+  extra="--no-overlap-train"; [ $tag = O ] && extra="--overlap-train"
   python tools/train_omok.py --out gpurun_out/r5zb_$tag --minutes ${MINUTES:-4} --board 9 --blocks 4 --sims 400 --games 2048 --steps 800 --batch 512 --resume profiles/r4_trained_9x9_4block.pt \
       --eval-every 1000 --ckpt-every 1000 $extra > gpurun_out/r5zb_$tag.log 2>&1
   python -c "$fmt" $tag < gpurun_out/r5zb_$tag/log.jsonl

@@ -60,9 +60,12 @@ def main():
     ap.add_argument("--ckpt-every", type=int, default=10)
     ap.add_argument("--max-ckpts", type=int, default=6, help="checkpoints kept on disk besides iteration 0 and final (gpurun_out is merged back up to 64 MiB)")
     ap.add_argument("--host-states", action="store_true", help="build the samples' state planes on the host and upload them (main.DEVICE_STATES = False): the path before device-side sample emission")
-    ap.add_argument("--overlap-train", action="store_true",
-                    help="main.train_async: an iteration's training pass runs on a worker thread and a side stream while the NEXT iteration's "
-                         "games are played with the weights exported before it started (one more iteration of staleness than carry-over already has)")
+    ap.add_argument("--overlap-train", action="store_true", default=True,
+                    help="(default since the end of round 5) main.train_async: an iteration's training pass runs on a worker thread and a side stream "
+                         "while the NEXT iteration's games are played with the weights exported before it started (one more iteration of staleness "
+                         "than carry-over already has; profiles/r5zb_overlap_train.txt, r5zz_overlap_learning_check.txt)")
+    ap.add_argument("--no-overlap-train", dest="overlap_train", action="store_false",
+                    help="the reference's alternation: the games wait for main.train (main.py:377-414)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--resume", default=None, help="state_dict to start from")
     a = ap.parse_args()
