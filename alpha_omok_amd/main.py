@@ -95,7 +95,7 @@ CARRY_CALLS = 2              # ... of at most this many calls ahead
 OVERLAP_TRAIN = False        # configure(overlap_train=True): run() trains on a worker thread + side stream WHILE the next iteration's games are
                              # played (train_async / train_join); 'serial' = the same deferred schedule without the thread (tests)
 played_ahead = [0]           # carry-over + overlapped training: searches made for LATER calls' games while a call that was complete waited for the pass
-_train_job = None            # the training pass in flight (train_async): dict(thread, plan, losses, error, wait_s)
+_train_job = None            # the training pass in flight (train_async): dict(thread, plan, n_epochs, losses, error, done)
 _train_stream = None
 last_train_losses = None     # losses of the pass train_join() finished last (self_play joins silently)
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
