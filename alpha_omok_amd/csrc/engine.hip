@@ -27,6 +27,7 @@ void launch_select(const TreeParams& p, hipStream_t s);
 void launch_expand_backup(const TreeParams& p, hipStream_t s);
 void launch_expand_select(const TreeParams& p, hipStream_t s);
 void launch_begin_move(const TreeParams& p, hipStream_t s);
+void launch_order(const TreeParams& p, int32_t* order, hipStream_t s);
 void launch_end_move(const TreeParams& p, hipStream_t s);
 void launch_play(const TreeParams& p, hipStream_t s);
 void launch_walk(const TreeParams& p, int count, const int32_t* games, const int32_t* extra, int stride, const int32_t* m,
@@ -68,6 +69,8 @@ struct ao_engine {
     // of the move (and when the ring wraps); row_cap = rows one simulation may take (0: as many as there are active games)
     static constexpr int kLive = 2048;
     unsigned* d_live = nullptr;
+    int32_t* d_order = nullptr;      // [G] launch order of k_expand_select's slots for over-subscribed searches (k_order, per move); AO_TREE_ORDER=0: off
+    bool order_on = true;
     unsigned* h_live = nullptr;                           // pinned [kLive]
     unsigned* d_ctl = nullptr;                            // [2][4] the sit-out window of the current / the next launch (tree_device.hpp, sit_window)
     int row_cap = 0;
@@ -288,7 +291,9 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     p.u8_row = A <= 128 ? 128 : 256;
     if (dev_alloc(e, &e->d_planes_u8, static_cast<size_t>(Gp) * p.u8_row) || dev_alloc(e, &e->d_row, 2 * static_cast<size_t>(G))) return 1;
     if (dev_alloc(e, &e->d_mt_backup, static_cast<size_t>(G) * 624) || dev_alloc(e, &e->d_pos_backup, G)) return 1;
-    if (dev_alloc(e, &e->d_live, ao_engine::kLive) || dev_alloc(e, &e->d_log_games, G) || dev_alloc(e, &e->d_ctl, 8)) return 1;
+    if (dev_alloc(e, &e->d_live, ao_engine::kLive) || dev_alloc(e, &e->d_log_games, G) || dev_alloc(e, &e->d_ctl, 8) || dev_alloc(e, &e->d_order, G)) return 1;
+    e->order_on = !(getenv("AO_TREE_ORDER") && atoi(getenv("AO_TREE_ORDER")) == 0);
+    p.order = nullptr;
     AO_HIP(e, hipMemsetAsync(e->d_row, 0, sizeof(int32_t) * 2 * G, e->stream));
     AO_HIP(e, hipMemsetAsync(e->d_live, 0, sizeof(unsigned) * ao_engine::kLive, e->stream));
     p.row_of_game = nullptr;
@@ -583,6 +588,7 @@ int ao_begin_move(ao_engine* e, const uint8_t* active) {
     AO_HIP(e, hipMemcpyAsync(p.sims_target, target, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(p.gflags, flags, sizeof(int32_t) * G, hipMemcpyHostToDevice, e->stream));
     AO_HIP(e, hipMemcpyAsync(e->d_active, e->active.data(), G, hipMemcpyHostToDevice, e->stream));
+    if (e->order_on && e->row_cap > 0 && e->row_cap < G) ao::launch_order(p, e->d_order, e->stream);   // (reads the move's stats that the next line clears)
     AO_HIP(e, hipMemsetAsync(p.stats, 0, sizeof(unsigned) * 4 * G, e->stream));
     ao::launch_begin_move(p, e->stream);
     // the pinned staging buffers are reused by the next call: make sure the copies are done
@@ -777,6 +783,7 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     // leaves), measured over the previous move of this engine, less three standard deviations of that binomial; the window moves on
     // by its own length per launch (see select_game). `unfinished` = games that still need simulations.
     const bool oversub = dynamic && cap_rows < rows;
+    p.order = (oversub && e->order_on && e->row_cap > 0 && e->row_cap < e->G) ? e->d_order : nullptr;
     static const int level_budget = getenv("AO_DESCENT_BUDGET") ? atoi(getenv("AO_DESCENT_BUDGET")) : 0;   // experiment: levels of a descent per launch
     p.max_levels = dynamic ? level_budget : 0;
     const bool catch_up = oversub || p.max_levels > 0;   // games may be short of their simulations after the nominal number of launches

@@ -80,6 +80,7 @@ struct TreeParams {
     int32_t* sims_target; int32_t* sims_done;
     int32_t* gflags;      // bit0: apply re-noise in begin_move (host-owned)
     int32_t* rstatus;     // root status after k_play: 0 fresh, 1 known/unexpanded, 2 expanded
+    const int32_t* order; // [G] k_expand_select: slot -> game, the deepest descents of the previous move first (k_order; over-subscribed searches only) or nullptr
     int compact_always;   // developer switch (AO_COMPACT_ALWAYS): re-root by copying after every move, as rounds 1 - 5 did
     int32_t* pending_root;  // [G] 1 + the node (current arena) k_play / k_walk chose as the next root; k_reroot copies its subtree and clears it (0: nothing to do)
     // per simulation scratch

@@ -54,9 +54,12 @@ __global__ __launch_bounds__(64 * kGamesPerWG) void k_expand_select(TreeParams p
     __shared__ int16_t s_tab[kGamesPerWG][256];
     __shared__ unsigned s_need[kGamesPerWG + 1];
     const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
-    const int g = blockIdx.x * kGamesPerWG + w;
-    const bool exists = g < p.G;
+    const int slot = blockIdx.x * kGamesPerWG + w;
+    const bool exists = slot < p.G;
     if (!exists && !p.live) return;
+    // (over-subscribed searches: more games than the chip holds waves, so the last workgroups start when the first ones retire --
+    // the games whose descents were deepest in the previous move are dispatched first, k_order)
+    const int g = (exists && p.order) ? __builtin_amdgcn_readfirstlane(p.order[slot]) : slot;
     unsigned sit_n, sit_off;
     sit_window(p, sit_n, sit_off);
     AO_TT(0);
@@ -506,6 +509,35 @@ void launch_expand_select(const TreeParams& p, hipStream_t s) {
     }
 #endif
 }
+// ----------------------------------------------------------------------------------------------
+// k_order: launch order of the next move's k_expand_select slots. An over-subscribed engine holds more games (5120) than the chip holds
+// tree waves (4096 at 4 per SIMD): the last fifth of the workgroups starts when earlier ones retire, and a launch lasts as long as
+// its deepest descent -- a deep game that starts late sets the launch's length (134 against 115 us for 4096 games).
+// A game's depth is a property of its position (a forced line stays 40 - 55 levels deep for hundreds of simulations), so the levels it
+// walked in the move that just ended (p.stats, about to be cleared) rank the next move's descents: 256 classes by share of the
+// maximum, deepest first; the order inside a class is whatever the atomics give. Nothing a game computes depends on its slot.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_order(TreeParams p, int32_t* order) {
+    constexpr int kClasses = 256;
+    __shared__ unsigned s_max, s_cnt[kClasses], s_cur[kClasses];
+    const int t = threadIdx.x;
+    if (t == 0) s_max = 0;
+    if (t < kClasses) s_cnt[t] = 0;
+    __syncthreads();
+    unsigned m = 0;
+    for (int g = t; g < p.G; g += 1024) { const unsigned l = p.stats[static_cast<size_t>(g) * 4]; m = l > m ? l : m; }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const unsigned long long mx = static_cast<unsigned long long>(s_max) + 1ull;
+    auto cls = [&](int g) { return kClasses - 1 - static_cast<int>(p.stats[static_cast<size_t>(g) * 4] * static_cast<unsigned long long>(kClasses) / mx); };
+    for (int g = t; g < p.G; g += 1024) atomicAdd(&s_cnt[cls(g)], 1u);
+    __syncthreads();
+    if (t == 0) { unsigned a = 0; for (int b = 0; b < kClasses; ++b) { s_cur[b] = a; a += s_cnt[b]; } }
+    __syncthreads();
+    for (int g = t; g < p.G; g += 1024) order[atomicAdd(&s_cur[cls(g)], 1u)] = g;
+}
+void launch_order(const TreeParams& p, int32_t* order, hipStream_t s) { hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, s, p, order); }
+
 void launch_begin_move(const TreeParams& p, hipStream_t s) {
     AO_DISPATCH_NCH(nch_of(p), hipLaunchKernelGGL(k_begin_move<NCH>, dim3(p.G), dim3(64), 0, s, p));
 }
