@@ -161,7 +161,8 @@ def test_row_assignments_agree_for_every_game_fused_vs_stepwise_vs_per_simulatio
       B  the step-wise protocol (begin_move / collect_leaves / net / apply_evals) -- the path the older deep-tree tests check,
       C  ao_search, rows handed out per simulation by the tree kernel (ao_set_row_cap(G): terminal leaves take no row),
       D  the same over-subscribed (640 rows for up to 1024 games: a share of the games sits out each launch, leaves that find
-         the batch full wait one launch; more launches per move).
+         the batch full wait one launch; more launches per move; its k_expand_select slots are dispatched in k_order's order --
+         the games with the deepest descents of the previous move first -- which must not matter to any game either).
     13 plies of the trained network with games ending and being retired.
     Second case: 4096 games in the default mode, where all four run the RESIDENT trunk (k_trunk16hb / k_trunk16h, >= 192 groups;
     its result for a board does not depend on the board's row or neighbours either): the kernel of the headline, reading the live-row
