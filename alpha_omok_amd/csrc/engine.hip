@@ -635,6 +635,17 @@ static int check_game_errors(ao_engine* e) {
         if (herr[g] & ao::ERR_NODE_CAP) m += " tree arena full (raise ao_config.node_cap)";
         if (herr[g] & ao::ERR_PATH) m += " no selectable child (priors are NaN: the policy summed to 0 over the legal moves -- the reference's prior /= prior.sum(), agents.py:189 -- or the tree is inconsistent)";
         if (herr[g] & ao::ERR_BAD_MOVE) m += " move onto an occupied cell";
+        if (herr[g] & ao::ERR_SHORT) {
+            // the reference always runs num_mcts simulations (agents.py:105-132): a pi from fewer visits is never handed out
+            int32_t dt[2] = {0, 0};
+            (void)hipMemcpy(&dt[0], e->tp.sims_done + g, sizeof(int32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&dt[1], e->tp.sims_target + g, sizeof(int32_t), hipMemcpyDeviceToHost);
+            int nshort = 0, nact = 0;
+            for (int k = 0; k < e->G; ++k) { nshort += (herr[k] & ao::ERR_SHORT) ? 1 : 0; nact += e->active[k] ? 1 : 0; }
+            m += " search ended after " + std::to_string(dt[0]) + " of " + std::to_string(dt[1]) + " simulations (" + std::to_string(nshort) + " of " +
+                 std::to_string(nact) + " active games are short; rows per simulation: " +
+                 (e->row_cap > 0 ? std::to_string(e->row_cap) : std::string("one per game")) + ")";
+        }
         // leave the engine usable: the error words are cleared and no move is in flight (the caller resets the game)
         (void)hipMemsetAsync(e->tp.err, 0, sizeof(int32_t) * e->G, e->stream);
         (void)hipStreamSynchronize(e->stream);
@@ -814,10 +825,11 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         std::memcpy(&init[2], &sf, 4);
         AO_HIP(e, hipMemcpyAsync(e->d_ctl, init, 8 * sizeof(unsigned), hipMemcpyHostToDevice, e->stream));
     }
+    bool sit_off_forced = false;   // the catch-up loop below: nobody sits out any more
     auto set_sit = [&](int i) {
-        p.ctl = oversub ? e->d_ctl : nullptr;
+        p.ctl = (oversub && !sit_off_forced) ? e->d_ctl : nullptr;
         p.ctl_cur = i & 1;
-        p.live_prev = (oversub && i > 0) ? slot(i - 1) : nullptr;
+        p.live_prev = (oversub && i > 0 && i % ao_engine::kLive != 0) ? slot(i - 1) : nullptr;   // (the ring was zeroed at a wrap: no demand reading for that launch)
         p.row_target = row_target;
     };
     // sums up the row counters of the selection launches [harvested, upto) -- each of them was followed by a network launch
@@ -909,13 +921,23 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
     if (catch_up) {
         // over-subscribed: leaves that found their simulation's batch full were expanded one launch later, so some games are
         // short of their simulations. The counters say by how much; max(largest deficit, all deficits / rows per launch)
-        // is a lower bound of the launches still needed -- run them, look again.
+        // is a lower bound of the launches still needed -- run them, look again. The reference ALWAYS runs num_mcts simulations
+        // (agents.py:105-132), so the loop ends in exactly two ways: every active game has its simulations, or an error. A round
+        // without progress is not a stall yet -- a leaf that waited takes its row in one launch and is expanded by the next, and a
+        // game may have sat out the only launch of the round -- so the sit-out window is switched OFF first (nobody sits out, and
+        // every round runs two launches at least); two more rounds without progress after that are a real stall. Whatever is still
+        // short when the loop ends is reported by k_end_move (ERR_SHORT) -- no result is built from fewer visits than asked for.
         const int G = e->G;
         int32_t* h_done = e->h_i32;
         int32_t* h_target = e->h_i32 + G;
         int32_t* h_err = e->h_i32 + 2 * G;
         int64_t last_sum = -1;
-        for (int round = 0; round < 4 * (e->S + 2); ++round) {
+        const char* dev_env = getenv("AO_CATCHUP_ROUNDS");   // developer switch, read per search: cut the loop short (tests: 0 = a short search must be an error)
+        const int dev_rounds = dev_env ? atoi(dev_env) : -1;
+        const int max_rounds = dev_rounds >= 0 ? dev_rounds : 4 * (e->S + 2);
+        bool window_off = false;
+        int stalled = 0;
+        for (int round = 0; round < max_rounds; ++round) {
             AO_HIP(e, hipMemcpyAsync(h_done, e->tp.sims_done, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
             AO_HIP(e, hipMemcpyAsync(h_target, e->tp.sims_target, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
             AO_HIP(e, hipMemcpyAsync(h_err, e->tp.err, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));
@@ -930,9 +952,16 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
                 if (d > 0) { sum += d; mx = std::max(mx, d); }
             }
             if (mx == 0 || bad) break;                      // done / a per-game error (reported by ao_end_move)
-            if (sum == last_sum && p.max_levels == 0) break;   // no progress (with a level budget a round may pass without a finished simulation)
+            if (sum == last_sum && p.max_levels == 0) {     // (with a level budget a round may pass without a finished simulation)
+                if (!window_off) window_off = true;
+                else if (++stalled >= 2) break;             // a real stall: ao_end_move names the games
+            } else {
+                stalled = 0;
+            }
             last_sum = sum;
-            const int extra = std::max<int64_t>(mx, (sum + cap_rows - 1) / cap_rows);
+            if (window_off) sit_off_forced = true;
+            int extra = static_cast<int>(std::max<int64_t>(mx, (sum + cap_rows - 1) / cap_rows));
+            if (window_off) extra = std::max(extra, 2);
             for (int k = 0; k < extra && rc == 0; ++k) rc = one_sim();
             if (rc) return rc;
         }

@@ -40,7 +40,7 @@ constexpr int32_t CH_TERMINAL = -2;   // visited child whose position ends the g
 enum : int32_t { LS_IDLE = 0, LS_EXPAND = 1, LS_EXPAND_ROOT = 2, LS_TERMINAL = 3, LS_WAIT = 4, LS_WAIT_ROOT = 5, LS_DESCEND = 6 };
 
 // per-game error bits
-enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4 };
+enum : int32_t { ERR_NODE_CAP = 1, ERR_PATH = 2, ERR_BAD_MOVE = 4, ERR_SHORT = 8 };   // ERR_SHORT: ao_end_move on a game short of its simulations
 
 // Everything a tree kernel needs, passed by value.
 //

@@ -107,6 +107,13 @@ __global__ __launch_bounds__(64) void k_end_move(TreeParams p) {
     const int g = blockIdx.x;
     const int lane = lane_id();
     if (p.active && !p.active[g]) return;
+    // The reference's search always runs its num_mcts simulations (agents.py:105-132): a game that is short of them -- a caller that
+    // ends the move early, an over-subscribed search that left its catch-up loop -- gets an error word instead of a pi, and its
+    // stream is not touched.
+    if (p.sims_done[g] != p.sims_target[g]) {
+        if (lane == 0) atomicOr(&p.err[g], ERR_SHORT);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int a = lane + 64 * c;

@@ -22,23 +22,27 @@ class Evaluator:
         self._bufs = None
         self._warned_width = False
         self._frozen = False   # freeze(): searches keep the weights exported last, whatever happens to the module (main.train_async)
+        self.strict_native = False   # True: a PVNet the native forward cannot take raises instead of running on its torch module
         self.net_mode = 0      # ao_net_set_mode of the exported network (6: one kernel family for every batch size)
 
     def native_net(self, model, board_size, inplanes):
         if self._frozen and self._net is not None:
             return self._net
         cfg = pvnet.looks_like_pvnet(model)
-        if cfg is not None and pvnet.native_width(cfg[2]) % 32 and cfg[3] == board_size and cfg[1] == inplanes:
+        if cfg is None or cfg[3] != board_size or cfg[1] != inplanes:
+            return None
+        if not pvnet.native_supported(cfg[2]):
             # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward covers up to 256 (other widths zero-padded to
-            # the next multiple of 32, pvnet.pad_state_dict)
+            # the next multiple of 32, pvnet.pad_state_dict). Wider networks: INTEGRATION.md, "Network widths".
+            if self.strict_native:
+                raise ValueError("PVNet with %d planes has no native MI355X forward (up to %d planes) and strict_native is set"
+                                 % (cfg[2], pvnet.NATIVE_MAX_PLANES))
             if not self._warned_width:
                 import warnings
                 warnings.warn("PVNet with %d planes: the native MI355X forward covers up to 256 planes -- this network "
                               "is evaluated by its own torch module, one call per simulation on the whole leaf batch "
                               "(correct, but several times slower than the MFMA kernels)" % cfg[2], RuntimeWarning, stacklevel=3)
                 self._warned_width = True
-            return None
-        if cfg is None or pvnet.native_width(cfg[2]) % 32 or cfg[3] != board_size or cfg[1] != inplanes:
             return None
         width = pvnet.native_width(cfg[2])
         # the native copy is keyed on the module OBJECT (held through a weak reference: a new module
@@ -101,7 +105,7 @@ class Evaluator:
         import torch
         dev = torch.device("cuda", self.device)
         G, C, B, A = eng.G, eng.inplanes, eng.board_size, eng.A
-        if self._bufs is None or self._bufs[0].shape[0] != G:
+        if self._bufs is None or tuple(self._bufs[0].shape) != (G, C, B, B):
             self._bufs = (torch.zeros((G, C, B, B), dtype=torch.float32, device=dev),
                           torch.zeros((G, A), dtype=torch.float32, device=dev),
                           torch.zeros((G,), dtype=torch.float32, device=dev))

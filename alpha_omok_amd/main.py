@@ -110,7 +110,8 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 40 % of the HBM
     holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
     strict=True makes self_play raise TreeTrimmed when re-rooting had to forget subtrees (otherwise a warning is
-    logged and `trim_stats` / self_play's return value carry the counters). reproducible=True evaluates every batch
+    logged and `trim_stats` / self_play's return value carry the counters) and checks after every search that each game's
+    visit counts sum to inherited + n_mcts (_check_visits). reproducible=True evaluates every batch
     size with ONE kernel family (ao_net_set_mode 6): an episode's samples then depend on its seed only, not on how many
     other episodes share the engine or on MAX_CONCURRENT (slower for very small and very large batches).
     carry_over=True keeps the engine full across self_play calls: a slot whose game ends when no episode of the current
@@ -268,6 +269,28 @@ def _check_trim(eng):
         logging.warning(msg)
 
 
+def _check_visits(eng, vis, act, on, inherit, fp16_seen):
+    """configure(strict=True): every search ran ALL its simulations (agents.py:105-132) -- visit.sum() is N_MCTS for a fresh root
+    and inherited + N_MCTS for a root that was a child of the last one (the child was expanded by the first
+    of its n visits, so it brings n - 1). The C side already refuses to end a move that is short (ERR_SHORT); this is the same
+    statement made from the outside, on what the caller is handed. Updates `inherit` for the next ply; returns the engine's
+    fp16-range event count (a move repeated on the fp32-MFMA trunk starts from fresh trees: nothing inherited)."""
+    ev = eng.fp16_range_events()[0]
+    if fp16_seen is None:
+        fp16_seen = ev
+    got = vis[on].sum(axis=1)
+    want = (inherit[on] if ev == fp16_seen else 0) + N_MCTS
+    if not np.array_equal(got, want):
+        bad = np.flatnonzero(got != want)
+        g = int(on[bad[0]])
+        from .engine import EngineError
+        raise EngineError("self-play: the search of game slot %d returned %d visits, %d expected (%d inherited + %d simulations); "
+                          "%d of %d searches of this ply are off" % (g, int(got[bad[0]]), int(np.broadcast_to(want, got.shape)[bad[0]]),
+                                                                     int(inherit[g]) if ev == fp16_seen else 0, N_MCTS, bad.size, on.size))
+    inherit[on] = np.maximum(vis[on, act[on]] - 1, 0)
+    return ev
+
+
 def _play_episodes(episodes, use_global, seed_of):
     """Plays the listed episodes on one engine (G = min(len, MAX_CONCURRENT) slots, finished slots refilled).
     Returns (moves [E, A] int32 (-1 padded), lengths [E], wins [E], ep_of [N], ply_of [N], pis [N, A] float64):
@@ -297,17 +320,22 @@ def _play_episodes(episodes, use_global, seed_of):
     active = np.ones(G, np.uint8)
     ply = np.zeros(G, np.int64)
     hist = []                                             # per search: (rows [n], plies [n], pi [n, A]) of the active slots
+    inherit = np.zeros(G, np.int64)                       # strict mode: visits the next root of each slot brings along
+    fp16_seen = eng.fp16_range_events()[0]
     trace = [] if os.environ.get("AO_SELFPLAY_TRACE") else None   # (active games, seconds) per search, for tools/time_self_play.py
     while active.any():
         tau = (ply < TAU_THRES).astype(np.int8)           # main.py:150-153
         t_search = time.perf_counter()
         _set_rows(eng)
-        pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=active)
+        pi, vis, _ = _evaluator.search(eng, Agent.model, tau, active=active)
         _count_search(eng)
         act, win = eng.play()                             # utils.get_action + env.step
         if trace is not None:
             trace.append((int(active.sum()), time.perf_counter() - t_search))
         on = np.flatnonzero(active)
+        if STRICT:
+            _check_trim(eng)                              # (a trimmed re-rooting is reported as what it is, not as a visit mismatch)
+            fp16_seen = _check_visits(eng, vis, act, on, inherit, fp16_seen)
         rows = slot_row[on]
         hist.append((rows, ply[on].copy(), pi[on]))
         moves[rows, ply[on]] = act[on]
@@ -327,6 +355,7 @@ def _play_episodes(episodes, use_global, seed_of):
                     active[g] = 0
                     slot_row[g] = -1
                 ply[g] = 0
+                inherit[g] = 0
             if refill.any():
                 eng.reset(refill)                         # Agent.reset() (main.py:248)
                 gs = np.flatnonzero(refill)
@@ -358,6 +387,8 @@ class _CarryPool:
         self.ply = np.zeros(self.G, np.int64)
         self.active = np.zeros(self.G, np.uint8)
         self.slot_moves = np.full((self.G, A), -1, np.int32)
+        self.inherit = np.zeros(self.G, np.int64)         # strict mode (_check_visits)
+        self.fp16_seen = None                             # ... the engine's fp16-range event count, taken at the first search
         self.finished = {}                                # global id -> (moves [A], length, win)
         self.hist = []                                    # (ids [n], plies [n], pi [n, A]) per search
         self.expect = None                                # first global id of the call expected next
@@ -414,6 +445,7 @@ def _play_carry(first_episode, n_call, rank, world):
             pool.active[mask != 0] = 1
             pool.ply[mask != 0] = 0
             pool.slot_moves[mask != 0] = -1
+            pool.inherit[mask != 0] = 0
 
     start(np.flatnonzero(pool.active == 0))
     trace = [] if os.environ.get("AO_SELFPLAY_TRACE") else None
@@ -432,12 +464,15 @@ def _play_carry(first_episode, n_call, rank, world):
         tau = (pool.ply < TAU_THRES).astype(np.int8)      # main.py:150-153
         t_search = time.perf_counter()
         _set_rows(eng)
-        pi, _, _ = _evaluator.search(eng, Agent.model, tau, active=pool.active)
+        pi, vis, _ = _evaluator.search(eng, Agent.model, tau, active=pool.active)
         _count_search(eng)
         act, win = eng.play()
         if trace is not None:
             trace.append((int(pool.active.sum()), time.perf_counter() - t_search))
         on = np.flatnonzero(pool.active)
+        if STRICT:
+            _check_trim(eng)
+            pool.fp16_seen = _check_visits(eng, vis, act, on, pool.inherit, pool.fp16_seen)
         pool.hist.append((pool.slot_id[on].copy(), pool.ply[on].copy(), pi[on]))
         pool.slot_moves[on, pool.ply[on]] = act[on]
         pool.ply[on] += 1

@@ -84,6 +84,14 @@ class PVNet(nn.Module):
         return net
 
 
+NATIVE_MAX_PLANES = 256
+
+
+def native_supported(planes):
+    """True when the HIP forward takes a `planes`-wide network (zero-padded to the next multiple of 32 if need be)."""
+    return 1 <= int(planes) <= NATIVE_MAX_PLANES
+
+
 def native_width(planes):
     """The width the HIP forward runs a `planes`-wide network at: the next multiple of 32 (at most 256), or `planes` itself when
     the native kernels cannot take it (wider than 256: the caller's torch module evaluates it)."""

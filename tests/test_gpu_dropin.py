@@ -69,11 +69,17 @@ def test_zero_agent_native_pvnet_path():
     agent.model = model
     np.random.seed(3)
     root = (0,)
+    inherited = 0
     for t in range(3):
         pi = agent.get_pi(root, 1)
-        assert agent.get_visit().sum() == (S if t == 0 else agent.get_visit().sum())
+        # agents.py:105-132: S simulations on top of what the root brings along -- the child that becomes the next root was
+        # expanded by the first of its n visits, so it inherits n - 1 (visit.sum() = S, then inherited + S)
+        vis = agent.get_visit()
+        assert vis.sum() == inherited + S, (t, vis.sum(), inherited)
         assert abs(pi.sum() - 1) < 1e-12
-        root = root + (int(np.argmax(pi)),)
+        a = int(np.argmax(pi))
+        inherited = max(int(vis[a]) - 1, 0)
+        root = root + (a,)
     assert agent._evaluator.native_net(model, B, 5) is not None
     p, v = agent.get_pv(root)
     with torch.no_grad():

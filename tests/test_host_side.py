@@ -502,6 +502,29 @@ def test_pad_state_dict_keeps_the_function():
         assert float((p0 - p1).abs().max()) < 1e-6 and float((v0 - v1).abs().max()) < 1e-6
 
 
+def test_wide_networks_take_the_module_path_loudly():
+    """model.PVNet takes any `planes` (model.py:76-85); the native forward stops at 256. A wider network -- multiples of 32 included
+    (round-5 advisor finding: 288 / 320 / 512 reached ao_net_create and raised) -- is evaluated by its own torch module after ONE
+    RuntimeWarning, or raises at once with strict_native. Decided before any GPU call."""
+    import warnings
+    from alpha_omok_amd.evaluator import Evaluator
+    from alpha_omok_amd.pvnet import PVNet, native_supported
+    assert [native_supported(p) for p in (1, 20, 256, 257, 288, 320, 512)] == [True, True, True, False, False, False, False]
+    for planes in (288, 300, 512):
+        ev = Evaluator(0)
+        m = PVNet(1, 5, planes, 5)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert ev.native_net(m, 5, 5) is None
+            assert ev.native_net(m, 5, 5) is None
+        assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == 1
+        ev.strict_native = True
+        with pytest.raises(ValueError, match="no native MI355X forward"):
+            ev.native_net(m, 5, 5)
+    # another board / plane count than the engine's: not a PVNet for this engine, no warning
+    assert Evaluator(0).native_net(PVNet(1, 5, 512, 5), 9, 5) is None
+
+
 def test_lazy_samples_unpack_like_the_tuples_they_stand_for():
     """main.self_play with rep_memory on the device appends utils.LazySamples to cur_memory: entries that count, unpack, index
     and stack like (state, pi, z) of main.py:159-166, with the state rebuilt (get_state_pt, utils.py:139-168) on first access."""
