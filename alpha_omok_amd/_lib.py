@@ -84,6 +84,7 @@ SYMBOLS = {
     "ao_net_get_mode": (C.c_int, [_vp]),
     "ao_net_status": (C.c_int, [_vp, _vp, _i32p, C.c_int]),
     "ao_net_conv_timing": (C.c_int, [_vp, C.c_int, _f64p, _i64p]),
+    "ao_net_products": (C.c_int, [_vp, C.c_int32, _i32p, _i32p]),
     "ao_net_dominant_kernel": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _f64p]),
     "ao_net_plan_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _f64p]),
     "ao_replay_create": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, _P(_vp)]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libomok_hip.so")
-SOURCES = ["tree_kernels.hip", "step_kernels.hip", "engine.hip", "net.hip", "replay.hip", "rollout.hip"]
+SOURCES = ["tree_kernels.hip", "step_kernels.hip", "engine.hip", "net.hip", "net_w16.hip", "replay.hip", "rollout.hip"]
 # every header under csrc/ (listed from the directory, so a new kernel header can never be missing from the staleness
 # check or from source_hash() -- round 4 shipped net_layer_ksplit.hpp outside this list) + the C ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(INC, "omok_hip.h")]

@@ -361,6 +361,7 @@ int ao_create(const ao_config* cfg, ao_engine** out) {
 // ---- RNG -------------------------------------------------------------------------------------
 int ao_set_rng_state(ao_engine* e, int g, const uint32_t* mt, int32_t pos, int32_t has_gauss, double gauss) {
     if (g < 0 || g >= e->G) return e->fail("game index out of range");
+    if (e->in_move) return e->fail("ao_set_rng_state / ao_seed inside a move (the move's Dirichlet draw has already consumed the old stream)");
     AO_HIP(e, hipSetDevice(e->cfg.device));
     AO_HIP(e, hipMemcpyAsync(e->tp.mt + static_cast<size_t>(g) * 624, mt, sizeof(uint32_t) * 624,
                              hipMemcpyHostToDevice, e->stream));
@@ -392,6 +393,7 @@ int ao_seed(ao_engine* e, int g, uint32_t seed) {
 int ao_seed_games(ao_engine* e, const int32_t* games, const uint32_t* seeds, int32_t n) {
     AO_HIP(e, hipSetDevice(e->cfg.device));
     if (n <= 0) return 0;
+    if (e->in_move) return e->fail("ao_seed_games inside a move");
     for (int k = 0; k < n; ++k)
         if (games[k] < 0 || games[k] >= e->G) return e->fail("ao_seed_games: game index out of range");
     AO_HIP(e, hipStreamSynchronize(e->stream));   // (the pinned staging rows are free)
@@ -410,6 +412,7 @@ int ao_seed_games(ao_engine* e, const int32_t* games, const uint32_t* seeds, int
 }
 
 int ao_seed_all(ao_engine* e, const uint32_t* seeds) {
+    if (e->in_move) return e->fail("ao_seed_all inside a move");
     AO_HIP(e, hipSetDevice(e->cfg.device));
     AO_HIP(e, hipStreamSynchronize(e->stream));
     for (int g = 0; g < e->G; ++g) {

@@ -25,6 +25,7 @@
 #include "net_layer_ksplit.hpp"
 #include "net_board_h16.hpp"
 #include "net_small.hpp"
+#include "net_w16.hpp"
 
 
 // ==============================================================================================
@@ -98,6 +99,10 @@ struct ao_net {
     double ms_total = 0.0;
     int64_t launches = 0;
     int last_in_kind = 1;                          // input of the most recent forward: 1 fp32 plane batch, 2 the engine's bit planes
+    // Two products instead of three (net_trunk_h16.hpp, W16): every conv weight x its layer's power of two is an fp16 number --
+    // found out by ao_net_finalize, per export. products_req: 0 = use it when the weights allow, 3 = always three (ao_net_products)
+    bool w16 = false;
+    int products_req = 0;
     int trunk_fmt = -1;                            // activation format inside the resident split-fp16 trunk (kPairBytes): 0 = two fp16 halves (default), 1 = fp16 high half + one low byte (AO_TRUNK_FMT=1)
 
     int fail(const std::string& m) { err = m; return 1; }
@@ -191,6 +196,9 @@ static bool board_resident(const ao_net* n, int boards) {
 static bool h16_supported(const ao_net* n) {
     return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
+// the two-product kernels run (the resident trunk in its default activation format, k_layer16h's trunk layers, k_boardh; every
+// other split-fp16 kernel keeps its three products -- on such weights the same bits)
+static bool two_products(const ao_net* n) { return n->w16 && n->products_req != 3; }
 
 namespace ao {
 
@@ -579,6 +587,11 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             const dim3 grid(groups * nchh * nxt), block(512);
             const bool timed = n->timing && l > 0;
             const int idx = timed ? timer_begin(n, s) : 0;
+            if (l > 0 && two_products(n)) {
+                NET_HIP(n, ao::launch_layer16h_w16(n->device, n->B, xt, grid, s, a));
+                if (timed) timer_end(n, idx, s);
+                return 0;
+            }
 #define AO_LAYERH_LAUNCH(W, XT_)                                                                                       \
     do {                                                                                                               \
         constexpr int NX_ = (XT_ < W) ? XT_ + 2 : XT_;                                                                 \
@@ -633,6 +646,9 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             // (the kernel deals boards to workgroups in rounds of 8 groups -- a group's 16 boards on one XCD --, so the grid covers whole rounds)
             const dim3 grid(std::min((boards + 127) / 128 * 128, n->num_cu)), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
+            if (two_products(n)) {
+                NET_HIP(n, ao::launch_boardh_w16(n->device, n->B, bits, grid, s, a));
+            } else
             switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W: {                                                                                                          \
@@ -691,6 +707,10 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.layers[l].ovf = n->d_status;
         }
         const int idx = n->timing ? timer_begin(n, s) : 0;
+        if (two_products(n) && n->trunk_fmt != 1) {
+            if (n->B > 9) return n->fail("split-fp16 trunk: board larger than 9x9");
+            NET_HIP(n, ao::launch_trunk16h_w16(n->device, n->B, in_kind, groups, s, a));
+        } else
         switch (n->B) {
 #define AO_BW_CASE(W)                                                                                        \
     case W: {                                                                                                \
@@ -1057,7 +1077,14 @@ int ao_net_finalize(ao_net* n) {
         n->conv_w.push_back(dw); n->conv_sc.push_back(dsc); n->conv_sh.push_back(dsh);
         if (l == 0 && (upload(n, &n->conv0_w16, pk[0].w16) || upload(n, &n->conv0_w1, pk[0].w1))) return 1;
     }
+    n->w16 = false;
     if (h16) {
+        // all low halves zero <=> w * 2^sft is an fp16 number for every conv weight of the network (conv1 included)
+        bool all_zero = true;
+        for (int l = 0; l < nl && all_zero; ++l)
+            for (uint16_t v : pk[l].lo)
+                if (v & 0x7fffu) { all_zero = false; break; }
+        n->w16 = all_zero;
         for (int l = 0; l < nl; ++l) {
             std::vector<float> sc, sh;
             if (fold_bn(n, pk[l].bn, P, &sc, &sh)) return 1;
@@ -1223,17 +1250,19 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
              ", waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
     } else if (group == 16 && mode == 5 && board_resident(n, boards)) {
-        nm = "k_boardh<" + bw + (in_kind == 2 ? ", 2" : ", 1") + "> (" + (in_kind == 2 ? "conv1 + " : "") + std::to_string(2 * n->nb) +
-             " 3x3 convs in one launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
+        nm = std::string(two_products(n) ? "k_boardh_w16<" : "k_boardh<") + bw + (in_kind == 2 ? ", 2" : ", 1") + "> (" + (in_kind == 2 ? "conv1 + " : "") + std::to_string(2 * n->nb) +
+             " 3x3 convs in one launch as split-fp16 MFMA 16x16x32 (" + (two_products(n) ? "2 products: the conv weights are fp16 numbers" : "3 products") + ", fp32 accumulate): "
              "a workgroup = one board resident in LDS through all layers, the row's cells as the MFMA N dimension, column shifts as DPP row shifts)";
         f = 2.0 * n->nb * 2.0 * n->A * 9.0 * n->planes * n->planes * boards + (in_kind == 2 ? 2.0 * n->A * 9.0 * n->C * n->planes * boards : 0.0);
     } else if (group == 16 && mode == 5 && (layers_only(n) || !(n->B <= 9 && (boards + 15) / 16 >= 192))) {
-        nm = "k_layer16h<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate), "
+        nm = std::string(two_products(n) ? "k_layer16h_w16<" : "k_layer16h<") + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (" +
+             (two_products(n) ? "2 products: the conv weights are fp16 numbers" : "3 products") + ", fp32 accumulate), "
              "16-board groups x row chunks x column tiles)";
         f = conv;
     } else if (group == 16 && mode == 5) {
-        nm = std::string(in_kind == 2 ? "k_trunk16hb<" : "k_trunk16h<") + bw + ", 4, " + std::to_string(n->trunk_fmt) + "> (conv1 + " +
-             std::to_string(2 * n->nb) + " 3x3 convs as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate) + heads, one resident "
+        const bool two = two_products(n) && n->trunk_fmt != 1;
+        nm = std::string(in_kind == 2 ? "k_trunk16hb" : "k_trunk16h") + (two ? "_w16<" : "<") + bw + ", 4, " + std::to_string(n->trunk_fmt) + "> (conv1 + " +
+             std::to_string(2 * n->nb) + " 3x3 convs as split-fp16 MFMA 16x16x32 (" + (two ? "2 products: the conv weights are fp16 numbers" : "3 products") + ", fp32 accumulate) + heads, one resident "
              "launch; activations between layers as " + (n->trunk_fmt == 1 ? "fp16 high half + one low byte" : "two fp16 halves") + ")";
         f = conv1 + 2.0 * n->nb * conv;
     } else if (group == 16) {
@@ -1253,6 +1282,14 @@ static void copy_name(const std::string& nm, char* name, int name_cap) {
         std::strncpy(name, nm.c_str(), static_cast<size_t>(name_cap) - 1);
         name[name_cap - 1] = 0;
     }
+}
+
+int ao_net_products(ao_net* n, int32_t request, int32_t* in_force, int32_t* weights_fp16) {
+    if (request != -1 && request != 0 && request != 3) return n->fail("ao_net_products: request must be -1 (query), 0 (automatic) or 3");
+    if (request != -1) n->products_req = request;
+    if (in_force) *in_force = two_products(n) ? 2 : 3;
+    if (weights_fp16) *weights_fp16 = n->w16 ? 1 : 0;
+    return 0;
 }
 
 int ao_net_dominant_kernel(ao_net* n, int boards, char* name, int name_cap, double* flop_per_launch) {

@@ -66,8 +66,10 @@ __device__ __forceinline__ half8 dpp_shift_h8(const half8 v) {
 
 // IN: 2 = conv1 runs here, on the engine's bit planes (ao_search); 1 = conv1 ran as k_layer16h on the fp32 plane batch (ao_net_forward
 // takes any float planes) and its output is gathered from the group layout
-template <int BW, int IN>
-__global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
+// W16: the conv weights are fp16 numbers (zero low halves): two products per multiply-add, no low weight fragments (36 registers
+// less) -- see TrunkHLayerFn
+template <int BW, int IN, bool W16>
+__device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
     static_assert(BW >= 10 && BW <= 15, "rows are padded to 16 cells and need at least one zero pad");
     __shared__ uint8_t s_pl[256];                  // IN 2: the board's plane bytes
     constexpr int A = BW * BW;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 ah[t] = __builtin_bit_cast(half8, a.layers[0].wh[(t * NT + tile) * 64 + lane]);
-                al[t] = __builtin_bit_cast(half8, a.layers[0].wl[(t * NT + tile) * 64 + lane]);
+                if (!W16) al[t] = __builtin_bit_cast(half8, a.layers[0].wl[(t * NT + tile) * 64 + lane]);
             }
             const float4 sc1 = a.layers[0].sc[tile * 4 + kq], sh1 = a.layers[0].sh[tile * 4 + kq];
             __syncthreads();
@@ -140,8 +142,10 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                     }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], xb[j], c[j], 0, 0, 0);
+                    if (!W16) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], xb[j], c[j], 0, 0, 0);
+                        for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], xb[j], c[j], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
             for (int t = 0; t < 9; ++t) {
                 const int ub = ((t * NCI + kb) * NT + tile) * 1024;
                 w9[0][t] = buf_ld_h8(r_h, lane16, ub);
-                w9[1][t] = buf_ld_h8(r_l, lane16, ub);
+                if (!W16) w9[1][t] = buf_ld_h8(r_l, lane16, ub);
             }
         };
         load_w9(a.layers[1], 0);
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
                     xl[2] = AO_BKO == 1 ? xl[1] : dpp_shift_h8<kDppRowShl1>(xl[1]);
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr) {          // products xh*wh, xh*wl, xl*wh
+                        if (W16 && pr == 1) continue;         // (wl == 0)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
@@ -283,6 +288,15 @@ __global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
         }
     }
     if (peak > 65504.f) atomicOr(a.layers[1].ovf, 1);
+}
+
+template <int BW, int IN>
+__global__ __launch_bounds__(512, 1) void k_boardh(BoardHArgs a) {
+    boardh_body<BW, IN, false>(a);
+}
+template <int BW, int IN>
+__global__ __launch_bounds__(512, 1) void k_boardh_w16(BoardHArgs a) {   // launched from net_w16.hip
+    boardh_body<BW, IN, true>(a);
 }
 
 }  // namespace ao

@@ -34,9 +34,9 @@ __device__ __forceinline__ float block_reduce(float v, float* s_red, bool is_max
 }
 
 #ifdef AO_PROF
-__device__ unsigned long long ao_prof_conv[8];    // k_conv_cells, block 0: wave 0 start / operands landed / MFMAs done / reduced / stored
+static __device__ unsigned long long ao_prof_conv[8];    // k_conv_cells, block 0: wave 0 start / operands landed / MFMAs done / reduced / stored
 #define AO_CT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_conv[k] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ unsigned long long ao_prof_heads[8];   // phase ends of k_heads_board (thread 0 of board 0), shader-clock ticks
+static __device__ unsigned long long ao_prof_heads[8];   // phase ends of k_heads_board (thread 0 of board 0), shader-clock ticks
 #define AO_HT(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) ao_prof_heads[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define AO_HT(k)

@@ -58,7 +58,7 @@ __device__ __forceinline__ void buf_st_h4(half4 v, __amdgpu_buffer_rsrc_t r, int
 // phase timing of k_trunk16h (build with AO_EXTRA_FLAGS=-DAO_PROF; tools/time_net.py prints it): shader-clock
 // cycles per wave of one group, summed over the trunk layers: [0] row-0 staging, [1] slab loops, [2] row
 // epilogues, [3] row barriers, [4] last epilogue + layer boundary, [5] heads, [6] conv1 total
-__device__ unsigned long long ao_prof[8 * 12];
+static __device__ unsigned long long ao_prof[8 * 12];   // (static: the header is compiled into two translation units)
 #define AO_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
 #define AO_ACC(k, t0, t1) prof[k] += (t1) - (t0)
 #else
@@ -169,7 +169,12 @@ __device__ __forceinline__ unsigned lo8_word(float vs) {   // vs: scaled, clampe
     return (u + 15u + ((u >> 5) & 1u)) >> 5;
 }
 
-template <int BW, int NC32, int NCI, int KIND, int FMT = 0>
+// W16: every conv weight of the network (after its layer's power-of-two pre-scale) IS an fp16 number, so the low weight halves are
+// all zero and the xh * wl product adds exact zeros: it is left out -- TWO products per multiply-add, (xh + xl) * wh, the same
+// bits as the three-product form on such weights (an MFMA on a zero operand leaves its accumulator as it was), a third fewer
+// MFMAs on a power-limited kernel and no low-half weight loads. ao_net_finalize finds out (net.hip, Net::w16); checkpoints get
+// there by keeping their conv weights on the fp16 grid (tools/train_omok.py --fp16-grid-weights).
+template <int BW, int NC32, int NCI, int KIND, int FMT = 0, bool W16 = false>
 struct TrunkHLayerFn {
 static __device__ __forceinline__ void run(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES, uint4* s_x,
                                            int tile, int lane, unsigned long long* prof, const bool flip,
@@ -214,14 +219,14 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
         for (int dx = 0; dx < 3; ++dx) {
             const int ub = ((((flip ? 2 - dy : dy) * 3 + dx) * NCI + c) * NT + tile) * 1024;
             W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
-            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+            if (!W16) W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
         }
     };
     if (FIRST) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
-            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+            if (!W16) wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
         }
     }
     // conv1: one fragment = channels 8*kq .. 8*kq+7 of (cell, board b) = two float4 quads of the fp32 batch
@@ -483,6 +488,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
 #pragma unroll
                     for (int pr = 0; pr < NPR; ++pr) {
                         if (BITS && pr == 2) continue;   // bit planes are 0 / 1: their low halves are zero, no xl * wh product
+                        if (W16 && pr == 1) continue;    // fp16 weights: their low halves are zero, no xh * wl product
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
                             const int i = xi - dx + 1;
@@ -551,7 +557,7 @@ static __device__ __forceinline__ void run(const void* src, uint4* dst, const Tr
 // plus one halo column on each side = 7 cells = 56 KB, two of them 112 KB). Halo columns that fall off the
 // board are staged as zeros, so the MFMA stream needs no per-column conditions; halo rows are handled by the
 // slab conditions (uniform per row) exactly as in the fp32 row-chunk kernel.
-template <int BW, int XT, int NC32, int NCI, int KIND>
+template <int BW, int XT, int NC32, int NCI, int KIND, bool W16 = false>
 __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, const TrunkHLayer& L, const bool RES,
                                                    uint4* s_x, int tile, int lane, int x0, int yb, int ye) {
     constexpr bool FIRST = KIND != 0;
@@ -581,14 +587,14 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
         for (int dx = 0; dx < 3; ++dx) {
             const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
             W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
-            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+            if (!W16) W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
         }
     };
     if (FIRST) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             wres[0][t] = buf_ld_h8(rs_wh, lane16, (t * NT + tile) * 1024);
-            wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
+            if (!W16) wres[1][t] = buf_ld_h8(rs_wl, lane16, (t * NT + tile) * 1024);
         }
     }
     auto load_planes = [&](int cell, int split) -> half8 {   // split 0: high halves, 1: low halves (0 for 0/1 planes)
@@ -707,6 +713,7 @@ __device__ __forceinline__ void trunk_h_layer_tile(const void* src, uint4* dst, 
 #pragma unroll
                     for (int pr = 0; pr < NPR; ++pr) {
                         if (BITS && pr == 2) continue;   // (see trunk_h_layer)
+                        if (W16 && pr == 1) continue;
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
                             const int i = HALO ? j - dx : j - dx + 1;   // output cell of the tile fed through tap column dx
@@ -748,8 +755,8 @@ struct LayerHArgs {
     unsigned row_cap;
 };
 
-template <int BW, int XT, int NC32, int KIND>
-__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
+template <int BW, int XT, int NC32, int KIND, bool W16>
+__device__ __forceinline__ void layer16h_body(const LayerHArgs& a) {
     constexpr int A = BW * BW;
     constexpr int NXT = (BW + XT - 1) / XT;
     extern __shared__ __attribute__((aligned(16))) uint4 s_x[];
@@ -764,18 +771,28 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
     const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
     uint4* dst = a.dst + static_cast<size_t>(grp) * A * NC32 * 2 * 64;
     if (KIND == 2) {
-        trunk_h_layer_tile<BW, XT, NC32, 1, 2>(static_cast<const uint8_t*>(a.src) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), dst,
+        trunk_h_layer_tile<BW, XT, NC32, 1, 2, W16>(static_cast<const uint8_t*>(a.src) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), dst,
                                                a.layer, false, s_x, tile, lane, xt * XT, yb, ye);
     } else if (KIND == 1) {
-        trunk_h_layer_tile<BW, XT, NC32, 1, 1>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
+        trunk_h_layer_tile<BW, XT, NC32, 1, 1, W16>(static_cast<const float4*>(a.src) + static_cast<size_t>(grp) * A * 8 * 16, dst, a.layer,
                                                false, s_x, tile, lane, xt * XT, yb, ye);
     } else {
-        trunk_h_layer_tile<BW, XT, NC32, NC32, 0>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
+        trunk_h_layer_tile<BW, XT, NC32, NC32, 0, W16>(static_cast<const uint4*>(a.src) + static_cast<size_t>(grp) * A * NC32 * 2 * 64, dst,
                                                       a.layer, a.res != 0, s_x, tile, lane, xt * XT, yb, ye);
     }
 }
 
-template <int BW, int NC32, int INK, int FMT>   // INK: 1 fp32 plane batch, 2 bit planes (see trunk_h_layer); FMT: see kPairBytes
+template <int BW, int XT, int NC32, int KIND>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h(LayerHArgs a) {
+    layer16h_body<BW, XT, NC32, KIND, false>(a);
+}
+// the two-product form (see TrunkHLayerFn, W16): launched from net_w16.hip
+template <int BW, int XT, int NC32, int KIND>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_layer16h_w16(LayerHArgs a) {
+    layer16h_body<BW, XT, NC32, KIND, true>(a);
+}
+
+template <int BW, int NC32, int INK, int FMT, bool W16 = false>   // INK: 1 fp32 plane batch, 2 bit planes (see trunk_h_layer); FMT: see kPairBytes
 __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     static_assert(FMT == 0 || AO_SPLIT_BARRIER == 0, "the split row barrier is implemented for the 4-byte format only");
     constexpr int A = BW * BW;
@@ -797,10 +814,10 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     // conv1: fp32 planes -> x
     AO_T(t0);
     if (INK == 2)
-        TrunkHLayerFn<BW, NC32, 1, 2, FMT>::run(reinterpret_cast<const uint8_t*>(a.in0) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), bufA,
+        TrunkHLayerFn<BW, NC32, 1, 2, FMT, W16>::run(reinterpret_cast<const uint8_t*>(a.in0) + static_cast<size_t>(grp) * 16 * kPlaneRow(BW), bufA,
                                       a.layers[0], false, s_x, tile, lane, pp, false, s_cnt, 0u);
     else
-        TrunkHLayerFn<BW, NC32, 1, 1, FMT>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
+        TrunkHLayerFn<BW, NC32, 1, 1, FMT, W16>::run(a.in0 + static_cast<size_t>(grp) * A * 8 * 16, bufA, a.layers[0], false, s_x, tile, lane, pp, false,
                                       s_cnt, 0u);
     AO_T(t1);
     if (ko_fill) {   // data-like LDS rows for the trunk layers, never refreshed (see AO_KO)
@@ -814,7 +831,7 @@ __device__ __forceinline__ void trunk16h_body(const TrunkHArgs& a) {
     for (int l = 1; l < a.nlayers; ++l) {
         // l odd: first conv of a ResBlock (x -> t); l even: second conv (t -> x, + x in place)
         const bool second = (l & 1) == 0;
-        TrunkHLayerFn<BW, NC32, NC32, 0, FMT>::run(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
+        TrunkHLayerFn<BW, NC32, NC32, 0, FMT, W16>::run(second ? bufB : bufA, second ? bufA : bufB, a.layers[l], second, s_x, tile, lane, pp,
                                              (l & 1) != 0, s_cnt, static_cast<unsigned>(l) * BW);
     }
     AO_T(t2);
@@ -837,6 +854,15 @@ __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h(TrunkHArgs a) {
 template <int BW, int NC32, int FMT>
 __global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16hb(TrunkHArgs a) {
     trunk16h_body<BW, NC32, 2, FMT>(a);
+}
+// the two-product forms (see TrunkHLayerFn, W16): launched from net_w16.hip
+template <int BW, int NC32, int FMT>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16h_w16(TrunkHArgs a) {
+    trunk16h_body<BW, NC32, 1, FMT, true>(a);
+}
+template <int BW, int NC32, int FMT>
+__global__ __launch_bounds__(NC32 * 2 * 64, 1) void k_trunk16hb_w16(TrunkHArgs a) {
+    trunk16h_body<BW, NC32, 2, FMT, true>(a);
 }
 
 }  // namespace ao

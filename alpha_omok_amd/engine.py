@@ -109,6 +109,13 @@ class Net:
         self._check(self._L.ao_net_status(self._h, stream, C.byref(f), 1 if clear else 0), "ao_net_status")
         return f.value
 
+    def products(self, request=-1):
+        """(MFMA products per multiply-add in force: 2 or 3, True when the loaded conv weights are fp16 numbers) -- ao_net_products.
+        request 0: two products whenever the weights allow (default), 3: always three, -1: query only."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self._L.ao_net_products(self._h, int(request), C.byref(a), C.byref(b)), "ao_net_products")
+        return a.value, bool(b.value)
+
     def dominant_kernel(self, boards):
         """(name, algorithmic FLOPs per launch) of the kernel conv_timing() measures."""
         buf = C.create_string_buffer(256)

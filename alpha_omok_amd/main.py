@@ -65,7 +65,7 @@ TRAIN_STEPS = None      # train(): mini-batches per pass (None: the reference's 
 rep_memory = deque(maxlen=MEMORY_SIZE)
 cur_memory = utils.SampleQueue()   # the reference's deque (main.py:56) that can also hold a call's samples as ONE block (utils.LazySamples)
 step = 0
-skipped_steps = 0       # train_batch: mini-batches whose loss was not finite (one process only; see train_batch)
+skipped_steps = 0       # mini-batches whose gradient was not finite and that therefore contributed nothing (see train_batch); updated once per pass
 start_iter = 0
 total_epoch = 0
 result = {'Black': 0, 'White': 0, 'Draw': 0}
@@ -101,11 +101,13 @@ last_train_losses = None     # losses of the pass train_join() finished last (se
 _pool = None                 # games in flight between self_play calls (carry-over mode only)
 _terminal_share = 0.0        # terminal leaves / simulations of the last search (drives ROWS = 'auto')
 _carry_auto = False          # run() with GAMES_PER_ITER set and CARRY_OVER None
+FP16_GRID = False            # configure(fp16_grid_weights=True): the 3x3 conv weights of Agent.model are kept on the fp16 grid (see _grid_sync)
+_grid_masters = []           # ... [(parameter, fp32 master copy)]: Adam moves the master, the module holds its projection
 
 
 def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_planes=None, seed=None,
               model=None, gpu=None, noise=True, device_replay=False, node_cap=None, strict=None, reproducible=False,
-              carry_over=None, oversubscribe=None, rows=None, overlap_train=None):
+              carry_over=None, oversubscribe=None, rows=None, overlap_train=None, fp16_grid_weights=None):
     """Build `Agent`, `Agent.model` and `optimizer` (main.py:58-85). Call instead of editing constants.
     node_cap: expanded-node capacity of a game's tree arena (0 = 16*(n_mcts+1) where 40 % of the HBM
     holds that for all games, at least 4*(n_mcts+1); -1 = grow into the free HBM);
@@ -128,11 +130,18 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     overlap_train=True: run() does not wait for an iteration's training pass -- it runs on a worker thread and a side stream while
     the NEXT iteration's games are played with the weights exported before it started (train_async; the samples of those games are
     appended, and the new weights published, after train_join). One iteration more of the asynchronous-actor trade carry_over
-    already makes; one process per GPU as before (the pass's collectives are issued by the worker thread only)."""
+    already makes; one process per GPU as before (the pass's collectives are issued by the worker thread only).
+    fp16_grid_weights=True: the 3x3 conv weights of the network (model.py:6-10: conv1 and the ResBlocks' convs) are kept on the fp16
+    grid -- after every optimiser step the module's weights are the fp16 rounding of an fp32 master copy that Adam moves (the
+    gradient is taken at the rounded weights: straight-through). Such a network runs on the TWO-product split-fp16 kernels
+    (ao_net_products: a third fewer MFMAs, the same fp32-equivalent contraction). The state_dict stays the reference's wire format:
+    plain fp32 tensors whose conv entries happen to be fp16 numbers."""
     global BOARD_SIZE, N_MCTS, N_BLOCKS, IN_PLANES, OUT_PLANES, SEED, Agent, optimizer, device
     global _engine, _evaluator, _episodes_played, rep_memory, STRICT, NODE_CAP, CARRY_OVER, _pool, OVERSUBSCRIBE, ROWS, _terminal_share
-    global OVERLAP_TRAIN
+    global OVERLAP_TRAIN, FP16_GRID
     train_join()
+    if fp16_grid_weights is not None:
+        FP16_GRID = bool(fp16_grid_weights)
     if overlap_train is not None:
         if overlap_train not in (True, False, 'serial'):
             raise ValueError("overlap_train must be True, False or 'serial'")
@@ -177,6 +186,7 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     if hasattr(Agent.model, "parameters"):
         parallel.broadcast_parameters(Agent.model)
         optimizer = torch.optim.Adam(Agent.model.parameters(), lr=LR, weight_decay=L2, eps=1e-6)
+    _grid_sync()
     _engine = None
     _evaluator = Evaluator(gpu)
     _evaluator.net_mode = 6 if reproducible else 0
@@ -187,6 +197,39 @@ def configure(board_size=None, n_mcts=None, n_blocks=None, in_planes=None, out_p
     elif not isinstance(rep_memory, deque):
         rep_memory = deque(maxlen=MEMORY_SIZE)
     return Agent
+
+
+def _grid_sync():
+    """configure(fp16_grid_weights=True): (re)build the fp32 master copies of the 3x3 conv weights from what the module holds NOW
+    (fresh weights, a loaded checkpoint) and put the module on the fp16 grid. No-op when the switch is off or the model is not a
+    torch module."""
+    del _grid_masters[:]
+    if not FP16_GRID or Agent is None or not hasattr(Agent.model, "named_parameters"):
+        return
+    import torch
+    with torch.no_grad():
+        for name, p in Agent.model.named_parameters():
+            if p.dim() == 4 and p.shape[2] == 3 and p.shape[3] == 3:
+                _grid_masters.append((p, p.detach().clone()))
+                p.copy_(p.to(torch.float16).to(p.dtype))
+    if _evaluator is not None:
+        _evaluator.invalidate()
+
+
+def _optimizer_step():
+    """optimizer.step(); with fp16_grid_weights Adam updates the fp32 master copies (swapped in for the step) and the module gets
+    their fp16 rounding back -- everything enqueued, no read-back."""
+    if not _grid_masters:
+        optimizer.step()
+        return
+    import torch
+    with torch.no_grad():
+        for p, m in _grid_masters:
+            p.copy_(m)
+        optimizer.step()
+        for p, m in _grid_masters:
+            m.copy_(p)
+            p.copy_(p.to(torch.float16).to(p.dtype))
 
 
 def _get_engine(games):
@@ -618,7 +661,8 @@ def train_batch(batch, total=None):
     takes part in the collective). Local forward/backward, one all-reduce of the flattened gradient over
     the ranks (none with one process), Adam step. `total`: the number of samples ALL ranks put behind this step,
     when the caller knows it (train() does, from one agreement per pass) -- the all-reduce then needs no read-back.
-    Returns (loss, v_loss, p_loss) or None for an empty batch; `step` advances whenever any rank contributed."""
+    Returns (loss, v_loss, p_loss) -- device scalars, float() reads them -- or None for an empty batch; `step` advances
+    whenever any rank contributed."""
     global step
     import torch
     optimizer.zero_grad()
@@ -639,21 +683,54 @@ def train_batch(batch, total=None):
     _, contributors = parallel.allreduce_gradients(Agent.model, contributes=len(batch) > 0, weight=len(batch), total=total)
     if contributors == 0:
         return None
-    if len(batch) > 0 and parallel.world()[1] == 1 and not bool(torch.isfinite(loss)):
-        # -(pi * p.log()) is the reference's loss (main.py:296-299) and it is -inf * pi as soon as the softmax underflows to an
-        # exact 0 on a move the search visited; the reference would write NaN into every weight and carry on. One process:
-        # the step is skipped and counted (skipped_steps), the weights stay what they were. (Under torch.distributed the ranks'
-        # losses differ and the step stays enqueue-only: unguarded, as in the reference.)
-        global skipped_steps
-        skipped_steps += 1
-        logging.warning('train_batch: non-finite loss (%r), optimiser step skipped (%d so far)', float(loss), skipped_steps)
-        optimizer.zero_grad()
-        return None
-    optimizer.step()
+    # -(pi * p.log()) is the reference's loss (main.py:296-299) and it is -inf * pi as soon as the softmax underflows to an exact 0 on
+    # a move the search visited; the reference would write NaN into every weight and carry on. Here such a mini-batch contributes
+    # NOTHING: when the (all-reduced) gradient is not finite, all of it is replaced by zeros ON THE DEVICE before the optimiser step
+    # (Adam then coasts on its moments for one step; no weight can become NaN) -- no host synchronisation per step, and the same on
+    # every rank: the gradients are identical after the all-reduce, so the ranks agree without talking. The event is counted on
+    # the device and read back once per pass (`skipped_steps`, the pass's log line; _train_execute).
+    _zero_nonfinite_gradients()
+    _optimizer_step()
     step += 1
     if len(batch) > 0:
-        out = (loss.item(), v_loss.item(), p_loss.item())
+        out = _LossRecord((loss.detach(), v_loss.detach(), p_loss.detach()))
     return out
+
+
+class _LossRecord(tuple):
+    """(loss, v_loss, p_loss) of a mini-batch, still on the device: float(x) / np.array(...) read them back, and _train_execute does
+    that once per pass instead of once per step."""
+
+
+_skipped_dev = None          # device counter of the mini-batches whose gradient was not finite (see train_batch)
+
+
+def _zero_nonfinite_gradients():
+    global _skipped_dev
+    import torch
+    grads = [p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None]
+    if not grads:
+        return
+    finite = torch.isfinite(torch.stack(torch._foreach_norm(grads))).all()
+    if _skipped_dev is None or _skipped_dev.device != finite.device:
+        _skipped_dev = torch.zeros((), dtype=torch.int64, device=finite.device)
+    _skipped_dev += (~finite).to(torch.int64)
+    for g in grads:
+        g.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)    # (so that the multiplication below yields zeros, not NaN)
+    torch._foreach_mul_(grads, finite.to(grads[0].dtype))
+
+
+def _collect_skipped():
+    """Adds the device counter of skipped mini-batches to `skipped_steps` (one read-back) and returns how many were new."""
+    global skipped_steps
+    if _skipped_dev is None:
+        return 0
+    n = int(_skipped_dev.item())
+    _skipped_dev.zero_()
+    if n:
+        skipped_steps += n
+        logging.warning('train: %d mini-batch(es) of this pass had a non-finite gradient and contributed nothing (%d so far)', n, skipped_steps)
+    return n
 
 
 def train(n_epochs, n_iter):
@@ -678,11 +755,24 @@ def train(n_epochs, n_iter):
     return _train_execute(_train_plan(), n_epochs)
 
 
+def _pass_watchdog(what):
+    """Under torch.distributed every mini-batch of a pass is a collective: a rank that stops making progress there ends itself
+    (parallel.Watchdog, AO_WATCHDOG_S seconds without a finished mini-batch, default 120) and the process group's timeout
+    (parallel.init_from_env) takes the waiting peers down -- no rank is left blocked in an all-reduce. One process: nothing armed."""
+    stall = float(os.environ.get("AO_WATCHDOG_S", "120")) if parallel.world()[1] > 1 else 0.0
+    return parallel.Watchdog(stall, what)
+
+
 def _train_plan():
     """What a training pass needs from the CALLING thread: the number of mini-batches, the positions random.sample picks (the
     `random` stream is consumed here) and, under torch.distributed, the per-step sample totals all ranks agree on."""
     rank, world = parallel.world()
     on_device = hasattr(rep_memory, "batch")
+    with _pass_watchdog("planning a training pass (agreement on the mini-batch count)"):
+        return _train_plan_locked(rank, world, on_device)
+
+
+def _train_plan_locked(rank, world, on_device):
     if world == 1:
         n_steps = len(cur_memory) if TRAIN_STEPS is None else int(TRAIN_STEPS)
         n = BATCH_SIZE * n_steps
@@ -707,23 +797,40 @@ def _train_execute(plan, n_epochs, publish=True):
     """The mini-batches of a planned pass (main.py:266-336). publish=False (train_async's worker): the searches' native copy of the
     weights is NOT invalidated here -- train_join does that on the thread that runs the searches."""
     global total_epoch
+    with _pass_watchdog("training pass") as dog:
+        return _train_execute_watched(plan, n_epochs, publish, dog)
+
+
+def _train_execute_watched(plan, n_epochs, publish, dog):
+    global total_epoch
     n_steps, train_memory, totals = plan
     Agent.model.train()
     losses = []
     trained = False
     for epoch in range(n_epochs):
         for i in range(n_steps):
+            dog.beat("training pass, mini-batch %d of %d" % (i + 1, n_steps))
             batch = train_memory[i * BATCH_SIZE:(i + 1) * BATCH_SIZE]
             out = train_batch(batch, totals[i])
             if out is not None:
                 trained = True
                 losses.append(out)
                 if PRINT_SELFPLAY:
-                    print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *out))
+                    print('{:4} Step Loss: {:.4f}   Loss V: {:.4f}   Loss P: {:.4f}'.format(step, *[float(x) for x in out]))
         total_epoch += 1
         if losses:
-            m = np.mean(np.array(losses), axis=0)
+            import torch
+            done = len([x for x in losses if not isinstance(x, _LossRecord)])
+            if done < len(losses):                        # this epoch's records: ONE read-back for all of them
+                host = torch.stack([torch.stack(list(x)) for x in losses[done:]]).cpu().tolist()
+                losses[done:] = [tuple(h) for h in host]
+            with np.errstate(all='ignore'):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore', RuntimeWarning)
+                    m = np.nanmean(np.array(losses), axis=0)   # (a mini-batch whose loss was not finite is not part of the mean)
             logging.warning('{:2} Epoch Loss: {:.4f}   Loss_V: {:.4f}   Loss_P: {:.4f}'.format(total_epoch, *m))
+    _collect_skipped()
     parallel.average_buffers(Agent.model, contributes=trained)
     if publish and _evaluator is not None:
         _evaluator.invalidate()                           # the native copy of the weights is stale now
@@ -853,6 +960,7 @@ def load_data(model_path, dataset_path):
         state = Agent.model.state_dict()
         state.update(torch.load(model_path, map_location=device))
         Agent.model.load_state_dict(state)
+        _grid_sync()
         if _evaluator is not None:
             _evaluator.invalidate()
         name = os.path.basename(model_path)

@@ -26,22 +26,197 @@ def _collectives_on():
     return dist.is_available() and dist.is_initialized()
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment; no-op for a single process."""
+DEFAULT_TIMEOUT_S = 300.0    # collectives of a training run (AO_DIST_TIMEOUT overrides; bench.py asks for 40 s)
+
+
+def init_from_env(backend=None, timeout_s=None, pin=True):
+    """Initialise torch.distributed from torchrun's environment; no-op for a single process.
+
+    timeout_s: the process group's collective timeout (default AO_DIST_TIMEOUT or 300 s). A rank that died or hangs then takes its
+    peers down with it instead of leaving them blocked for torch's default 10 minutes (RCCL) / 30 minutes (gloo): under "nccl"
+    torch's watchdog aborts the process when a collective exceeds it, under "gloo" the collective raises. pin: bind this process
+    (and every thread it starts from here on: the engine's host pool, torch's intra-op threads) to the CPUs of its GPU's NUMA node
+    (pin_to_gpu_numa; AO_NO_AFFINITY=1 turns it off)."""
+    import datetime
     import torch.distributed as dist
     n = int(os.environ.get("WORLD_SIZE", "1"))
     if n <= 1 or dist.is_initialized():
         return world()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("AO_DIST_TIMEOUT", DEFAULT_TIMEOUT_S))
+    timeout = datetime.timedelta(seconds=float(timeout_s))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if pin and torch.cuda.is_available():
+        pin_to_gpu_numa(local % max(torch.cuda.device_count(), 1))
     if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        dist.init_process_group(backend, device_id=torch.device("cuda", local), timeout=timeout)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=timeout)
     return world()
+
+
+def set_collective_timeout(seconds):
+    """Tighten (or relax) the timeout of the default process group's collectives after start-up: rendezvous, RCCL's communicator
+    set-up over xGMI and the first page-in of a cold box want minutes, the steady state wants to notice a dead peer in seconds.
+    Returns True when the backend took it."""
+    import datetime
+    import torch.distributed as dist
+    if not _collectives_on():
+        return False
+    try:
+        dist.distributed_c10d._set_pg_timeout(datetime.timedelta(seconds=float(seconds)))
+        return True
+    except Exception:
+        return False
+
+
+# ---- host placement: one process per GPU, each on the NUMA node its GPU hangs off -------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' (the kernel's cpulist format) -> [0, 1, 2, 3, 8, 10, 11]."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def gpu_numa_cpus(pci_bus_id, sysfs="/sys"):
+    """(NUMA node, its CPUs) of the PCI device 'dddd:bb:dd.f', or (None, []) when the platform does not say (numa_node -1 on
+    single-node hosts, no sysfs). Looked up under /sys/bus/pci/devices first, then through /sys/class/drm/card*/device."""
+    pci_bus_id = pci_bus_id.lower()
+    cands = [os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id)]
+    drm = os.path.join(sysfs, "class", "drm")
+    try:
+        for card in sorted(os.listdir(drm)):
+            dev = os.path.join(drm, card, "device")
+            if card.startswith("card") and "-" not in card and os.path.basename(os.path.realpath(dev)).lower() == pci_bus_id:
+                cands.append(dev)
+    except OSError:
+        pass
+    for dev in cands:
+        try:
+            with open(os.path.join(dev, "numa_node")) as f:
+                node = int(f.read().strip())
+        except (OSError, ValueError):
+            continue
+        if node < 0:
+            return None, []
+        try:
+            with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+                return node, parse_cpulist(f.read())
+        except (OSError, ValueError):
+            return node, []
+    return None, []
+
+
+def device_pci_bus_id(local):
+    p = torch.cuda.get_device_properties(local)
+    return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+
+
+last_affinity = None     # what pin_to_gpu_numa did last: dict(numa_node, cpus, pci) or dict(skipped=reason)
+
+
+def pin_to_gpu_numa(local, sysfs="/sys", pci_bus_id=None):
+    """sched_setaffinity of the calling thread to the CPUs of GPU `local`'s NUMA node (intersected with what the process may use
+    already). Threads started afterwards inherit it: call before the first Engine is created (its host pool draws the Dirichlet
+    noise of thousands of games per move and stages 10 MB of MT19937 state per move through pinned memory: with eight ranks on a
+    two-socket host, half of them would otherwise do that across the socket link). Never fails: returns what it did."""
+    global last_affinity
+    if os.environ.get("AO_NO_AFFINITY"):
+        last_affinity = dict(skipped="AO_NO_AFFINITY")
+        return last_affinity
+    try:
+        pci = pci_bus_id or device_pci_bus_id(local)
+        node, cpus = gpu_numa_cpus(pci, sysfs)
+        if node is None or not cpus:
+            last_affinity = dict(skipped="no NUMA node reported for %s" % pci)
+            return last_affinity
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            last_affinity = dict(skipped="NUMA node %d has no CPU this process may use" % node)
+            return last_affinity
+        os.sched_setaffinity(0, allowed)
+        last_affinity = dict(numa_node=node, cpus=len(allowed), pci=pci)
+        # the engine's host pool (csrc/host_rng.hpp) budgets hardware threads / LOCAL_WORLD_SIZE: with the ranks bound to their
+        # nodes the share is this node's CPUs / the ranks that live on it
+        try:
+            n_local = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+            if n_local > 1 and "AO_HOST_THREADS" not in os.environ and pci_bus_id is None:
+                ndev = max(torch.cuda.device_count(), 1)       # (rank r drives device r % ndev: ranks may share a device in the tests)
+                node_of = [gpu_numa_cpus(device_pci_bus_id(d), sysfs)[0] for d in range(ndev)]
+                same = sum(1 for r_ in range(n_local) if node_of[r_ % ndev] == node)
+                os.environ["AO_HOST_THREADS"] = str(max(1, min(32, len(allowed) // max(same, 1))))
+                last_affinity["host_threads"] = int(os.environ["AO_HOST_THREADS"])
+        except Exception:
+            pass
+    except Exception as e:                                # (placement is an optimisation: never a reason to fail a run)
+        last_affinity = dict(skipped=repr(e))
+    return last_affinity
+
+
+# ---- a rank that stops making progress takes itself down (and, through the collective timeout, its peers) -------------------
+class Watchdog:
+    """Armed around the regions that issue collectives (bench.py's timed loop, main's training pass): beat() after every unit of
+    work; when no beat arrives for `stall_s` seconds a daemon thread prints what the rank was doing and ends the process with
+    exit code 86 -- a hung GPU queue or a peer that never shows up becomes a failed job in about a minute, not a node that sits
+    there until somebody looks. AO_WATCHDOG=0 disables it."""
+
+    def __init__(self, stall_s, what=""):
+        import threading
+        self.stall_s, self.what = float(stall_s), what
+        self._last = None
+        self._note = what
+        self._stop = threading.Event()
+        self._thread = None
+        self._lock = threading.Lock()
+
+    def beat(self, note=None):
+        import time
+        with self._lock:
+            self._last = time.monotonic()
+            if note is not None:
+                self._note = note
+
+    def __enter__(self):
+        import threading
+        if os.environ.get("AO_WATCHDOG", "1") != "0" and self.stall_s > 0:
+            self.beat()
+            self._stop.clear()
+            self._thread = threading.Thread(target=self._run, name="alpha_omok_amd.watchdog", daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+            self._thread = None
+        return False
+
+    def _run(self):
+        import sys
+        import time
+        while not self._stop.wait(min(1.0, self.stall_s / 4.0)):
+            with self._lock:
+                idle = time.monotonic() - self._last
+                note = self._note
+            if idle > self.stall_s:
+                r, w = world()
+                sys.stderr.write("alpha_omok_amd watchdog: rank %d of %d made no progress for %.0f s (%s) -- exiting with code 86 so that the "
+                                 "job fails instead of hanging\n" % (r, w, idle, note))
+                sys.stderr.flush()
+                os._exit(86)
 
 
 def shard_games(n_games, rank, world_size):

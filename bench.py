@@ -345,7 +345,7 @@ class TrainStep:
             self.ms.append((t1 - t0) * 1e3)
             self.export_ms.append((t2 - t1) * 1e3)
             if out is not None:
-                self.losses.append(out[0])
+                self.losses.append(float(out[0]))
 
     def allreduce_probe(self, dist, dev):
         """Isolated cost of the step's collective: the same flattened buffer, 20 repetitions."""
@@ -393,7 +393,7 @@ TIMING_STRIDE = 8
 TRAINED_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_trained_9x9_4block.pt")
 
 
-def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.25):
+def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.25, fp16_grid=False):
     """The headline workload with a TRAINED network (a checkpoint of tools/train_omok.py: this engine's own self-play +
     main.train on the MI355X) instead of random-init weights: sharp priors, so the searches go deep, meet terminal leaves
     and keep most of the tree from move to move -- the regime the tree kernels exist for. Fresh engine, `warm_plies`
@@ -404,14 +404,26 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
         keeps its stale row in the batch, so 11 - 19 % of the trunk's rows are junk with this network;
       * the result proper: `oversubscribe` x G games on the same G rows per simulation, handed out by the tree kernel per
         simulation (ao_set_row_cap(G): terminal leaves take none; a share of the games sits out each launch in turn) -- the
-        trunk launch is the same 256 groups, but every row is a live leaf. A step is still one move decision of every game."""
+        trunk launch is the same 256 groups, but every row is a live leaf. A step is still one move decision of every game.
+
+    fp16_grid (the `trained_net_fp16grid` leg): the same checkpoint with its 3x3 conv weights rounded to the fp16 grid -- what
+    tools/train_omok.py --fp16-grid-weights maintains during training (a relative change of <= 2^-11 per weight) -- so that the
+    library plans the TWO-product split-fp16 kernels (ao_net_products); only the over-subscribed run is made."""
     from alpha_omok_amd.engine import Engine
     from alpha_omok_amd.pvnet import PVNet
     B, S, G = args.board, args.sims, args.games
     model = PVNet(args.blocks, 5, args.planes, B)
     model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+    if fp16_grid:
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 4 and p.shape[2] == 3:
+                    p.copy_(p.to(torch.float16).to(p.dtype))
     model.eval()
     net = model.to_native(local)
+    products, weights_fp16 = net.products()
+    if fp16_grid and products != 2:
+        raise RuntimeError("the fp16-grid weights did not plan the two-product kernels (products %d, weights_fp16 %r)" % (products, weights_fp16))
     A_ = B * B
 
     def run(games, row_cap):
@@ -478,6 +490,13 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
              "rows_evaluated_per_simulation": (rs1["rows_live"] - rs0["rows_live"]) / sims_total if row_cap else 1.0,
              "trunk_kernel": kname.split(" (")[0], "trunk_avg_launch_ms": conv_ms / max(conv_n, 1),
              "trunk_time_share": conv_ms * TIMING_STRIDE * 1e-3 / dt,
+             # the conv stack against the dense fp16 MFMA peak, computed as the headline's roofline is: algorithmic FLOPs of a launch
+             # at the batch's CAPACITY (zero padding and empty rows counted as the headline counts them) / its average duration
+             "roofline": {"bound": "mfma", "kernel": kname.split(" (")[0], "products": products, "flop_per_launch": f_launch,
+                          "avg_launch_ms": conv_ms / max(conv_n, 1), "launches_timed": conv_n,
+                          "achieved": f_launch / (conv_ms / max(conv_n, 1) * 1e-3) / 1e12 if conv_n else 0.0, "peak": PEAK_F16_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": f_launch / (conv_ms / max(conv_n, 1) * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if conv_n else 0.0,
+                          "executed_tflops": products * f_launch / (conv_ms / max(conv_n, 1) * 1e-3) / 1e12 if conv_n else 0.0},
              "roofline_tree": {"kernel": "k_expand_select", "avg_launch_ms": tree_avg, "launches_timed": tree_n,
                                "algorithmic_bytes_per_launch": tree_bytes,
                                "achieved": tree_bytes / (tree_avg * 1e-3) / 1e9 if tree_n else 0.0, "unit": "GB/s", "peak": 8000.0,
@@ -492,13 +511,16 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
         eng.close()
         return r
 
-    static = run(G, 0)
+    static = run(G, 0) if not (fp16_grid and oversubscribe and oversubscribe > 1.0) else None
     over = run(int(round(G * oversubscribe / 256.0)) * 256, G) if oversubscribe and oversubscribe > 1.0 else None
     r = dict(over if over else static)
     r["weights"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    r["mfma_products"] = products
+    if fp16_grid:
+        r["weights"] += " with the 3x3 conv weights rounded to the fp16 grid (tools/train_omok.py --fp16-grid-weights keeps them there)"
     r["workload"] = ("the headline's sims / rows per simulation, network = the committed checkpoint trained by this engine "
                      "(tools/train_omok.py); plies %d-%d timed" % (warm_plies, warm_plies + steps - 1))
-    if over:
+    if over and static:
         r["static_rows"] = static
         r["vs_static_rows"] = over["value"] / static["value"]
     net.close()
@@ -559,6 +581,7 @@ def main():
     ap.add_argument("--oversubscribe", type=float, default=1.25, help="`trained_net` leg: games per row of the evaluation batch (1.25: 5120 games on "
                     "the 4096 rows per simulation the tree kernel hands out; 1: the per-move packing only)")
     ap.add_argument("--no-wide-board", action="store_true", help="skip the `wide_board` leg (BASELINE configs[4]'s per-GPU shape: 15x15, 10 blocks, 800 sims, 1024 games)")
+    ap.add_argument("--no-fp16-grid", action="store_true", help="skip the `trained_net_fp16grid` leg (the trained checkpoint with its conv weights on the fp16 grid: two-product kernels)")
     ap.add_argument("--no-trained-net", action="store_true", help="skip the `trained_net` leg (the headline workload with trained weights)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -577,7 +600,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    from alpha_omok_amd import parallel
+    affinity = None
+    # a rank that dies or hangs must fail the JOB, quickly: the process group's collective timeout takes the ranks that wait for it
+    # down (AO_DIST_TIMEOUT, 40 s once the warm-up is over; AO_DIST_INIT_TIMEOUT, 300 s, for rendezvous, RCCL's communicator set-up and
+    # a cold box's page-in), a watchdog thread ends a rank that itself stops making progress (AO_WATCHDOG_S, 50 s / 300 s at start-up)
+    steady_timeout = float(os.environ.get("AO_DIST_TIMEOUT", "40"))
+    steady_stall = float(os.environ.get("AO_WATCHDOG_S", "50"))
+    init_timeout = float(os.environ.get("AO_DIST_INIT_TIMEOUT", "300"))
+    dog = parallel.Watchdog(max(init_timeout, steady_stall) if world > 1 else 0.0, "start-up")
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # AO_BENCH_BACKEND=gloo + AO_BENCH_SHARE_GPU=1 exercise this path with two ranks on a 1-GPU box
@@ -585,10 +618,14 @@ def main():
         if os.environ.get("AO_BENCH_SHARE_GPU"):
             local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
+        # this rank's threads (the engine's host pool, torch's) on the NUMA node of its GPU (AO_NO_AFFINITY=1: off)
+        affinity = parallel.pin_to_gpu_numa(local)
+        timeout = datetime.timedelta(seconds=init_timeout)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
+    dog.__enter__()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -630,16 +667,31 @@ def main():
             next_seed[0] += world * gs.size
             ply[done] = 0
 
+    dog.beat("engine and network built")
     train_on = args.train_step == "on" or (args.train_step == "auto" and world > 1)
     trainer = TrainStep(args, model, local, rank, world, net) if train_on else None
+    dog.beat("replay shard filled")
+    ncycle = [0]
 
     def cycle(count):
         step(count)
         if trainer is not None:
             trainer.step(count)
+        ncycle[0] += 1
+        dog.beat("after step %d (%s)" % (ncycle[0], "timed" if count else "warm-up"))
 
     for _ in range(args.warmup):
         cycle(False)
+    if dist is not None:
+        dist.barrier()                                    # every rank is through its start-up: from here on a silent peer is a dead peer
+        parallel.set_collective_timeout(steady_timeout)
+        dog.stall_s = steady_stall
+        dog.beat("warm-up over, steady-state timeouts in force")
+    # developer switches of tests/test_gpu_multirank.py: rank r dies (exit code 9) / stops making progress after the warm-up
+    if os.environ.get("AO_BENCH_TEST_DIE_RANK") == str(rank):
+        os._exit(9)
+    if os.environ.get("AO_BENCH_TEST_HANG_RANK") == str(rank):
+        time.sleep(3600)
 
     def fence():
         eng.sync()
@@ -663,6 +715,20 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    dog.beat("timed region over")
+    # per-rank view of the same run (one small all-gather): the first multi-GPU record should show stragglers and clock spread,
+    # not just the maximum
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([dt / args.steps * 1e3, conv_ms / max(conv_launches, 1), tree_ms / max(tree_launches, 1)], dtype=torch.float64,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        rows = [[float(x) for x in g.cpu().tolist()] for g in got]
+        ms = [r_[0] for r_ in rows]
+        per_rank = {"ms_per_step": ms, "ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "slowest_rank": int(np.argmax(ms)),
+                    "fastest_rank": int(np.argmin(ms)), "trunk_avg_launch_ms": [r_[1] for r_ in rows],
+                    "tree_avg_launch_ms": [r_[2] for r_ in rows]}
     # what the collective library itself saw during the timed run: the group's size and backend, and the sum over the group of one
     # 1 per rank (the reduction just above ran on the same group) -- so that an N-GPU line proves RCCL ("nccl") had N ranks
     rccl_ranks = None
@@ -708,6 +774,8 @@ def main():
             "unit": "move-decisions/s",
             "n_gpus": world,
             "rccl_ranks": rccl_ranks,
+            "per_rank": per_rank,
+            "host_affinity": affinity,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
@@ -865,15 +933,53 @@ def main():
                                                   "achieved": fw / (aw * 1e-3) / 1e12 if cw_n else 0.0, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                   "frac": fw / (aw * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if cw_n else 0.0,
                                                   "traffic": other_workload_traffic(tj, csrc_sha, Bw, Gw, 10, args.planes, kw)}}
+                if not args.no_fp16_grid:
+                    # the same shape on weights rounded to the fp16 grid: k_boardh_w16, two products per multiply-add (fresh games, same seeds)
+                    with torch.no_grad():
+                        for p_ in mw.parameters():
+                            if p_.dim() == 4 and p_.shape[2] == 3:
+                                p_.copy_(p_.to(torch.float16).to(p_.dtype))
+                    netw = mw.to_native(local, netw)
+                    engw.reset()
+                    engw.seed_all(np.arange(11 * Gw, 12 * Gw, dtype=np.uint32))
+                    wstep()
+                    netw.conv_timing(True)
+                    engw.sync()
+                    torch.cuda.synchronize()
+                    tw0 = time.perf_counter()
+                    for _ in range(nw):
+                        wstep()
+                    engw.sync()
+                    torch.cuda.synchronize()
+                    dw2 = time.perf_counter() - tw0
+                    c2_ms, c2_n = netw.conv_timing(False)
+                    k2, f2 = netw.dominant_kernel(Gw)
+                    a2 = c2_ms / max(c2_n, 1)
+                    out["wide_board"]["fp16grid"] = {
+                        "weights": "the same random-init network with its 3x3 conv weights rounded to the fp16 grid", "mfma_products": netw.products()[0],
+                        "value": nw * Gw / dw2, "unit": "move-decisions/s", "ms_per_step": dw2 / nw * 1e3, "vs_three_products": dw / dw2,
+                        "roofline": {"bound": "mfma", "kernel": k2.split(" (")[0], "products": netw.products()[0], "flop_per_launch": f2, "avg_launch_ms": a2,
+                                     "launches_timed": c2_n, "achieved": f2 / (a2 * 1e-3) / 1e12 if c2_n else 0.0, "peak": PEAK_F16_MFMA_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": f2 / (a2 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if c2_n else 0.0}}
                 engw.close()
                 netw.close()
             except Exception as e:
-                out["wide_board"] = {"value": None, "error": repr(e)}
+                out.setdefault("wide_board", {"value": None})["error"] = repr(e)
         if world == 1 and not args.no_trained_net and os.path.exists(args.trained_weights) and (B, args.blocks, args.planes) == (9, 4, 128):
             try:
                 out["trained_net"] = trained_net_bench(args, local, args.trained_weights, oversubscribe=args.oversubscribe)
             except Exception as e:
                 out["trained_net"] = {"value": None, "error": repr(e)}
+            if not args.no_fp16_grid:
+                # the same leg on weights that sit on the fp16 grid: two MFMA products per multiply-add instead of three. NOT the
+                # headline (which stays the arbitrary-fp32 random-init network on three products); reported beside `trained_net`
+                try:
+                    leg = trained_net_bench(args, local, args.trained_weights, oversubscribe=args.oversubscribe, fp16_grid=True)
+                    if out["trained_net"].get("value"):
+                        leg["vs_trained_net"] = leg["value"] / out["trained_net"]["value"]
+                    out["trained_net_fp16grid"] = leg
+                except Exception as e:
+                    out["trained_net_fp16grid"] = {"value": None, "error": repr(e)}
         if world == 1 and G > 1 and not args.no_single_game:
             # BASELINE configs[1] beside the headline: ONE game, 400 sims/move, same network
             # (latency path: per-board conv kernels, no concurrency to hide behind)
@@ -911,9 +1017,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "move-decisions/s", "cores": None,
                                        "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
+    dog.beat("report printed")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    dog.__exit__(None, None, None)
 
 
 if __name__ == "__main__":

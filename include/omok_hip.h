@@ -229,6 +229,14 @@ int  ao_net_status(ao_net *n, void *stream, int32_t *flags, int clear);
 /* total device time (ms) and count of the TIMED launches of the dominant trunk kernel since the last call
  * (HIP events on the launch stream); used by bench.py's roofline. enable = n > 1: every n-th forward is timed. */
 int  ao_net_conv_timing(ao_net *n, int enable, double *ms_total, int64_t *launches);
+/* MFMA products per multiply-add of the split-fp16 conv kernels (model.py:6-31,97-104: the 3x3 convs of PVNet). The kernels
+ * compute x*w = xh*wh + xh*wl + xl*wh on fp16 halves of both operands (three products, fp32 accumulate). When every conv weight
+ * of the loaded network, scaled by its layer's power of two, IS an fp16 number -- ao_net_finalize checks, per export -- wl is zero
+ * everywhere and the middle product adds exact zeros: the two-product kernels leave it out (same bits, a third fewer MFMAs).
+ * request: 0 = two products whenever the weights allow (default), 3 = always three, -1 = query only. in_force: 2 or 3;
+ * weights_fp16: 1 when the loaded weights qualify. A checkpoint gets there by keeping its conv weights on the fp16 grid
+ * (tools/train_omok.py --fp16-grid-weights); nothing else about the state_dict changes. */
+int  ao_net_products(ao_net *n, int32_t request, int32_t *in_force, int32_t *weights_fp16);
 /* name and algorithmic FLOPs per launch (2*MAC, zero padding counted) of the kernel the timing
  * refers to, for a batch of `boards` positions. */
 int  ao_net_dominant_kernel(ao_net *n, int boards, char *name, int name_cap, double *flop_per_launch);

@@ -279,6 +279,36 @@ def test_bench_self_launches_two_ranks_with_training_step(tmp_path):
     ts = d["train_step"]
     assert ts["allreduce_ranks"] == 2 and ts["allreduce_backend"] == "gloo" and ts["train_steps"] == 2 and ts["inside_timed_region"]
     assert ts["allreduce_elements"] > 1000 and ts["mean_loss"] is not None and np.isfinite(ts["mean_loss"])
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and pr["ms_per_step_max"] == max(pr["ms_per_step"]) and pr["slowest_rank"] in (0, 1)
+    assert d["ms_per_step"] >= pr["ms_per_step_max"] * 0.999                # the reported time is the max over the ranks
+    assert len(pr["trunk_avg_launch_ms"]) == 2 and all(x > 0 for x in pr["trunk_avg_launch_ms"])
+
+
+@pytest.mark.parametrize("mode", ["DIE", "HANG"])
+def test_bench_fails_as_a_whole_when_one_rank_dies_or_hangs(mode):
+    """First 8-GPU contact, failure side: rank 1 dies (exit 9) or stops making progress right after the warm-up
+    (AO_BENCH_TEST_DIE_RANK / AO_BENCH_TEST_HANG_RANK). The job must END, non-zero, with no bench line: the peers' next barrier
+    runs into the steady-state collective timeout (AO_DIST_TIMEOUT), the hung rank's watchdog ends it (exit code 86), the launcher
+    reaps the rest. Without the timeouts rank 0 sat in its barrier for gloo's 30 minutes (RCCL: 10)."""
+    import subprocess
+    import sys
+    import time
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AO_BENCH_SHARE_GPU="1", AO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", AO_DIST_TIMEOUT="8", AO_WATCHDOG_S="10")
+    env["AO_BENCH_TEST_%s_RANK" % mode] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--games", "64",
+           "--sims", "16", "--blocks", "1", "--prefill-games", "3", "--prefill-sims", "8"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    wall = time.time() - t0
+    assert r.returncode != 0, "the job reported success although rank 1 was gone"
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "a bench line was printed by a job that lost a rank"
+    if mode == "HANG":
+        assert "made no progress" in r.stderr, r.stderr[-1500:]
+    # start-up (two imports of torch, engines, replay prefill) + at most timeout / watchdog + the launcher's clean-up
+    assert wall < 120.0, wall
 
 
 def test_bench_eight_rank_launch_shape_on_the_shared_gpu(tmp_path):
@@ -307,4 +337,11 @@ def test_bench_eight_rank_launch_shape_on_the_shared_gpu(tmp_path):
     assert ts["allreduce_ranks"] == 8 and ts["train_steps"] == 2 and ts["inside_timed_region"]
     assert ts["weights_identical_across_ranks"] is True
     assert ts["mean_loss"] is not None and np.isfinite(ts["mean_loss"])
-    assert d["config"]["host_threads_per_rank"] == max(1, min(32, (os.cpu_count() or 1) // 8))
+    aff = d.get("host_affinity") or {}
+    # (bound to its GPU's NUMA node a rank's share is that node's CPUs / the ranks on it; unbound: all CPUs / LOCAL_WORLD_SIZE)
+    assert d["config"]["host_threads_per_rank"] == (aff["host_threads"] if "host_threads" in aff else max(1, min(32, (os.cpu_count() or 1) // 8)))
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and len(pr["trunk_avg_launch_ms"]) == 8 and len(pr["tree_avg_launch_ms"]) == 8
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and 0 <= pr["slowest_rank"] < 8 and 0 <= pr["fastest_rank"] < 8
+    assert d["rccl_ranks"]["world_size"] == 8 and d["rccl_ranks"]["ranks_in_allreduce"] == 8
+    assert "host_affinity" in d                                             # (what pin_to_gpu_numa did on rank 0; None only at one rank)

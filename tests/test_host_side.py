@@ -713,3 +713,114 @@ def test_overlapped_training_schedule_and_host_logic(monkeypatch):
         main._train_job = None
         main.TRAIN_STEPS, main.BATCH_SIZE, main.OVERLAP_TRAIN = None, 32, False
         main.rep_memory.clear(); main.cur_memory.clear()
+
+
+def test_gpu_numa_mapping_and_pinning_from_a_fake_sysfs(tmp_path, monkeypatch):
+    """parallel.pin_to_gpu_numa (round-5 review, first 8-GPU contact): GPU -> PCI address -> numa_node -> cpulist -> sched_setaffinity,
+    looked up under /sys/bus/pci/devices or through /sys/class/drm/card*/device; platforms that report no node (-1) and the
+    AO_NO_AFFINITY switch leave the process alone. Host logic only: a fake sysfs tree."""
+    from alpha_omok_amd import parallel
+    assert parallel.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parallel.parse_cpulist("5") == [5] and parallel.parse_cpulist("") == []
+    root = tmp_path / "sys"
+    mine = sorted(os.sched_getaffinity(0))
+    node1 = mine[:max(1, len(mine) // 2)]
+
+    def cpulist(cpus):
+        return ",".join(str(c) for c in cpus) + "\n"
+    for node, cpus in ((0, [100000, 100001]), (1, node1)):
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpulist(cpus))
+    for pci, node in (("0000:05:00.0", 1), ("0000:85:00.0", 0), ("0000:c5:00.0", -1)):
+        d = root / "bus" / "pci" / "devices" / pci
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    # a device only reachable through the drm class links
+    real = root / "devices" / "pci0000:e0" / "0000:e5:00.0"
+    real.mkdir(parents=True)
+    (real / "numa_node").write_text("1\n")
+    drm = root / "class" / "drm"
+    drm.mkdir(parents=True)
+    (drm / "card3").mkdir()
+    os.symlink(str(real), str(drm / "card3" / "device"))
+    (drm / "card3-DP-1").mkdir()
+    assert parallel.gpu_numa_cpus("0000:05:00.0", str(root)) == (1, node1)
+    assert parallel.gpu_numa_cpus("0000:85:00.0", str(root)) == (0, [100000, 100001])
+    assert parallel.gpu_numa_cpus("0000:C5:00.0", str(root)) == (None, [])          # the platform says "no node"
+    assert parallel.gpu_numa_cpus("0000:e5:00.0", str(root)) == (1, node1)          # via /sys/class/drm/card3/device
+    assert parallel.gpu_numa_cpus("0000:ff:00.0", str(root)) == (None, [])
+    try:
+        r = parallel.pin_to_gpu_numa(0, str(root), pci_bus_id="0000:05:00.0")
+        assert r == dict(numa_node=1, cpus=len(node1), pci="0000:05:00.0") and sorted(os.sched_getaffinity(0)) == node1
+        os.sched_setaffinity(0, mine)
+        r = parallel.pin_to_gpu_numa(0, str(root), pci_bus_id="0000:85:00.0")    # a node whose CPUs this process may not use
+        assert "skipped" in r and sorted(os.sched_getaffinity(0)) == mine
+        r = parallel.pin_to_gpu_numa(0, str(root), pci_bus_id="0000:c5:00.0")
+        assert "skipped" in r and sorted(os.sched_getaffinity(0)) == mine
+        monkeypatch.setenv("AO_NO_AFFINITY", "1")
+        assert parallel.pin_to_gpu_numa(0, str(root), pci_bus_id="0000:05:00.0") == dict(skipped="AO_NO_AFFINITY")
+        assert sorted(os.sched_getaffinity(0)) == mine
+    finally:
+        os.sched_setaffinity(0, mine)
+
+
+_DEAD_PEER_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(repo)r)
+import torch
+import torch.distributed as dist
+from alpha_omok_amd import parallel
+rank = int(os.environ["RANK"])
+parallel.init_from_env("gloo", timeout_s=60, pin=False)
+t = torch.ones(4)
+dist.all_reduce(t)                                        # start-up: both ranks are there
+assert float(t[0]) == 2.0
+assert parallel.set_collective_timeout(4.0)
+mode = os.environ["AO_TEST_MODE"]
+with parallel.Watchdog(6.0, "test loop") as dog:
+    for i in range(1000):
+        if rank == 1 and i == 3:
+            if mode == "die":
+                os._exit(9)
+            time.sleep(3600)                              # "hang": no beats, no collectives
+        dist.all_reduce(t)
+        dog.beat("step %%d" %% i)
+        time.sleep(0.05)
+'''
+
+
+@pytest.mark.parametrize("mode", ["die", "hang"])
+def test_a_dead_or_hung_rank_fails_every_rank_quickly(tmp_path, mode):
+    """First-contact hardening (round-5 review): under torch.distributed a rank that raises or hangs used to leave its peers blocked
+    in their next all-reduce for torch's default 30 minutes (10 under RCCL). With parallel.init_from_env's timeout,
+    set_collective_timeout after start-up and parallel.Watchdog: rank 1 dies (exit 9) or stops making progress -- rank 0's next
+    collective fails within the timeout and it exits non-zero; a hung rank ends itself with exit code 86. Two plain processes, no
+    launcher that would clean up for them; gloo on CPU."""
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_DEAD_PEER_WORKER % dict(repo=REPO))
+    procs = []
+    t0 = time.time()
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   AO_TEST_MODE=mode)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        outs = [p.communicate(timeout=120) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    wall = time.time() - t0
+    rc = [p.returncode for p in procs]
+    assert rc[0] != 0, "rank 0 did not notice its peer: %r" % (outs[0][1][-500:],)
+    assert rc[1] == (9 if mode == "die" else 86), (rc, outs[1][1][-500:])
+    if mode == "hang":
+        assert "made no progress" in outs[1][1]
+    assert wall < 60.0, wall

@@ -683,7 +683,35 @@ def gv13():
     save("gv13_eval_head_to_head", **out)
 
 
-ALL = dict(gv13=gv13, gv12=gv12, gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
+def gv14():
+    """The reference's searches with the REAL network end to end (torch CPU, one thread): what `north_star`'s "visit counts and
+    chosen moves bit-exact" has to be measured against once the evaluations come from the native MI355X forward instead of a
+    replay (tests/test_gpu_realnet_drift.py). Visits / actions / stream positions only -- no recorded evaluations: 3 seeds x 6
+    plies with the random-init 4-block network of gv6 (torch.manual_seed(0)), 2 seeds x 6 plies with the trained 2-block fixture."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from make_trained_fixture import load
+    cases = []
+    torch.manual_seed(0)
+    net = ref_model.PVNet(4, 5, 128, 9)
+    net.eval()
+    for seed in (0, 1, 2):
+        recs, win = _play(9, 400, 0, seed, 6, model=net)
+        cases.append(((9, 400, -1, seed, 6, 6, 1), recs, win))
+        print("  gv14 random-init seed", seed, [r["action"] for r in recs])
+    tnet = ref_model.PVNet(2, 5, 128, 9)
+    tnet.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in load(os.path.join(OUT, "trained_2block_9x9.npz")).items()})
+    tnet.eval()
+    for seed in (0, 1):
+        recs, win = _play(9, 400, 0, seed, 6, model=tnet)
+        cases.append(((9, 400, -2, seed, 6, 6, 1), recs, win))
+        print("  gv14 trained seed", seed, [r["action"] for r in recs])
+    out = _pack(cases)
+    for k in [k for k in out if k.split("_", 1)[-1] in ("w", "q", "policy", "pi", "order")]:
+        del out[k]
+    save("gv14_realnet_visits", **out)
+
+
+ALL = dict(gv14=gv14, gv13=gv13, gv12=gv12, gv11=gv11, gv1=gv1, gv2=gv2, gv3=gv3, gv4=gv4, gv5=gv5, gv6=gv6, gv7=gv7, gv8=gv8, gv9=gv9,
            gv10=gv10)
 
 if __name__ == "__main__":

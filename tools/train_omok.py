@@ -66,6 +66,10 @@ def main():
                          "than carry-over already has; profiles/r5zb_overlap_train.txt, r5zz_overlap_learning_check.txt)")
     ap.add_argument("--no-overlap-train", dest="overlap_train", action="store_false",
                     help="the reference's alternation: the games wait for main.train (main.py:377-414)")
+    ap.add_argument("--fp16-grid-weights", action="store_true",
+                    help="keep the 3x3 conv weights on the fp16 grid (main.configure(fp16_grid_weights=True): fp32 master copies in Adam, the module holds "
+                         "their fp16 rounding) -- such a network runs on the two-product split-fp16 kernels (ao_net_products); the checkpoint stays a "
+                         "plain fp32 state_dict the reference loads")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--resume", default=None, help="state_dict to start from")
     a = ap.parse_args()
@@ -88,9 +92,11 @@ def main():
     if a.rows_per_sim:
         m.MAX_CONCURRENT = a.rows_per_sim
     m.configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, out_planes=a.planes, seed=a.seed,
-                device_replay=True, carry_over=not a.no_carry_over, oversubscribe=a.oversubscribe, rows=a.rows)
+                device_replay=True, carry_over=not a.no_carry_over, oversubscribe=a.oversubscribe, rows=a.rows,
+                fp16_grid_weights=a.fp16_grid_weights)
     if a.resume:
         m.Agent.model.load_state_dict(torch.load(a.resume, map_location=m.device))
+        m._grid_sync()                                   # (fp16-grid mode: masters = the loaded weights, module = their rounding)
     dev = m.device
     base = PVNet(a.blocks, m.IN_PLANES, a.planes, a.board).to(dev)
     base.load_state_dict(m.Agent.model.state_dict())
@@ -154,6 +160,7 @@ def main():
                    mean_select_depth=round(d["levels"] / max(d["evaluated"] + d["terminal"], 1), 3),
                    terminal_share=round(d["terminal"] / max(d["evaluated"] + d["terminal"], 1), 4),
                    trims=dict(m.trim_stats), node_cap=eng.node_cap()[0], fp16_range_events=ev, slots=eng.G, rows=eng.row_stats(),
+                   skipped_steps=m.skipped_steps, mfma_products=(m._evaluator._net.products()[0] if m._evaluator._net is not None else None),
                    replay=len(m.rep_memory), games_total=games_total, moves_total=moves_total)
         emit(rec)
         m.reset_iter(m.result, m.cur_memory)
