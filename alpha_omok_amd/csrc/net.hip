@@ -632,7 +632,8 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             BoardHArgs a;
             a.act = reinterpret_cast<const uint4*>(n->act_x);
             a.planes = reinterpret_cast<const uint8_t*>(in_il);
-            a.out = reinterpret_cast<float4*>(n->act_t);
+            a.hbuf = n->hbuf;
+            a.w3 = n->head_w3; a.sc3 = n->head_sc3; a.sh3 = n->head_sh3;
             a.nlayers = 1 + 2 * n->nb;
             a.nboards = boards;
             a.live = live; a.row_cap = row_cap;
@@ -669,10 +670,7 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             }
             if (n->timing) timer_end(n, idx, s);
             NET_HIP(n, hipGetLastError());
-            // the heads on the kernel's fp32 NHWC output: the batched head kernels with "groups" of one board
-            const int nchunk1 = (n->A + 255) / 256;
-            hipLaunchKernelGGL(k_head_conv<false>, dim3(boards * nchunk1), dim3(256), 3 * n->planes * sizeof(float), s,
-                               reinterpret_cast<const float4*>(n->act_t), n->head_w3, n->head_sc3, n->head_sh3, n->hbuf, n->A, n->CQ, 1);
+            // the FC layers of the heads on the kernel's hbuf (the 1x1 head convs ran in its last epilogue)
             const size_t lds1 = (static_cast<size_t>(4) * n->A + n->planes + 8) * sizeof(float);
             hipLaunchKernelGGL(k_head_fc, dim3(boards), dim3(256), lds1, s, n->hbuf, n->wp_t, n->bp, n->w1_t, n->b1, n->w2, n->b2, policy, value,
                                n->A, n->planes);

@@ -23,10 +23,10 @@
 //     place) -> barrier. The ResBlock input of a wave's own cout tile stays in its registers (60) across the block's two convs;
 //   * conv1 runs in the same launch on the engine's bit planes (ao_search; 90 MFMAs per wave, K = tap * 8 + plane) -- or, for
 //     ao_net_forward's arbitrary float planes, as k_layer16h<BW, ..., KIND 1> before it, its output gathered from the group layout
-//     (a group's 16 boards go to 16 workgroups of one XCD: they share every line). The output is written as fp32 NHWC, 64-byte
-//     segments, for the batched head kernels (k_head_conv / k_head_fc: 405 KB of policy_fc weights per board want the whole chip,
-//     not one workgroup -- run inside this kernel by heads_board_dev the heads cost 70 us per board, 0.28 ms per launch of 1024
-//     boards against 0.1 ms for the two batched launches): 23 launches become 3.
+//     (a group's 16 boards go to 16 workgroups of one XCD: they share every line). The heads' 1x1 convs (128 -> 3 channels) are
+//     taken from the last layer's registers (round 6: the trunk's output -- 118 MB of fp32 NHWC per 1024 boards -- is not written
+//     any more); the FC layers stay a batched launch (k_head_fc: 405 KB of policy_fc weights per board want the whole chip, not one
+//     workgroup -- run inside this kernel by heads_board_dev the heads cost 70 us per board): 23 launches become 2.
 // Same arithmetic family as the other split-fp16 kernels (3 products per multiply-add, fp32 accumulate, weights pre-scaled by a
 // power of two per layer); the summation order over taps / blocks differs, so results agree to fp32 rounding, not bit for bit.
 #pragma once
@@ -46,7 +46,8 @@ namespace ao {
 struct BoardHArgs {
     const uint4* act;    // IN 1: conv1's output in the group layout [group of 16][cell][block 4][half 2][oct 4][board 16] x 16 B (k_layer16h KIND 1)
     const uint8_t* planes;   // IN 2: the engine's bit planes, [board][kPlaneRow(BW)] bytes, bit q = plane q (tree_device.hpp encode_planes)
-    float4* out;         // [board][cell][32] float4: the trunk's output, fp32 NHWC (k_head_conv<false> with groups of ONE board reads it)
+    float* hbuf;         // [board][3][A]: the heads' 1x1 convs + BatchNorm + ReLU of the trunk's output (model.py:37-39,56-58), what k_head_fc reads
+    const float *w3, *sc3, *sh3;   // head conv weights [3][128] (policy 0, 1; value 2) and their folded BatchNorm
     int nlayers;         // 1 + 2 * n_block, conv1 included (layers[0]: its BatchNorm scale / shift for IN 2)
     int nboards;
     const unsigned* live;   // live rows of this simulation's batch (net_common.hpp) or null
@@ -88,6 +89,12 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
     // the lane's 8-byte slot inside output fragment (row, tile >> 1, half): cout quad q = kq -> k-octet (tile & 1) * 2 + (kq >> 1)
     const int out_off = (((tile & 1) * 2 + (kq >> 1)) * 16 + n) * 16 + (kq & 1) * 8;
     float peak = 0.f;
+    // the head convs' weights of this lane's four couts (tile * 16 + kq * 4 + c), three heads
+    float w3r[3][4];
+#pragma unroll
+    for (int h = 0; h < 3; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w3r[h][c] = a.w3[h * 128 + tile * 16 + kq * 4 + c];
     // Which board a workgroup carries: the 16 boards of a GROUP share every 128-byte line of the group layout (a board's share of a
     // line is 16 bytes), so they go to 16 workgroups of ONE XCD at the same time -- workgroups are dealt round robin over the 8 XCDs:
     // virtual index v = round * gridDim + blockIdx -> XCD x = v % 8, position j = v / 8: group (j / 16) * 8 + x, slot j % 16. A line
@@ -275,8 +282,26 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
                     hh[c] = static_cast<_Float16>(v[c]);
                     hl[c] = static_cast<_Float16>(v[c] - static_cast<float>(hh[c]));
                 }
-                if (last) {   // the trunk's output: fp32 NHWC in global memory (the heads below read it from L2)
-                    if (n < BW) a.out[(static_cast<size_t>(board) * A + y * BW + n) * 32 + tile * 4 + kq] = make_float4(v[0], v[1], v[2], v[3]);
+                if (last) {
+                    // The trunk's output never leaves the chip (round 6; it was 118 MB of fp32 NHWC per launch of 1024 boards for a
+                    // separate k_head_conv launch): the heads' 1x1 convs (128 -> 2 + 1 channels, model.py:37,56) are taken here, from
+                    // the registers -- this lane's four couts, then the four k-quads of the wave (lanes n, n + 16, n + 32, n + 48),
+                    // then, through the LDS the activations no longer need, the eight waves in a fixed order.
+                    float hs[3];
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) t = fmaf(v[c], w3r[h][c], t);
+                        t += __shfl_xor(t, 16);
+                        t += __shfl_xor(t, 32);
+                        hs[h] = t;
+                    }
+                    if (kq == 0 && n < BW) {
+                        float* part = reinterpret_cast<float*>(s_x);
+#pragma unroll
+                        for (int h = 0; h < 3; ++h) part[(tile * 3 + h) * A + y * BW + n] = hs[h];
+                    }
                     continue;
                 }
                 char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
@@ -285,6 +310,17 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
                 if (second) xres[y] = f32x4{v[0], v[1], v[2], v[3]};   // the next block's input
             }
             __syncthreads();
+            if (last) {
+                // the eight waves' partial head sums -> BatchNorm + ReLU -> hbuf (k_head_fc: the FC layers want the whole chip)
+                const float* part = reinterpret_cast<const float*>(s_x);
+                for (int i = threadIdx.x; i < 3 * A; i += 512) {
+                    const int h = i / A, cell = i - h * A;
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NT; ++w) t += part[(w * 3 + h) * A + cell];
+                    a.hbuf[static_cast<size_t>(board) * 3 * A + i] = fmaxf(fmaf(t, a.sc3[h], a.sh3[h]), 0.f);
+                }
+            }
         }
     }
     if (peak > 65504.f) atomicOr(a.layers[1].ovf, 1);

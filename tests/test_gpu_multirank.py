@@ -305,8 +305,8 @@ def test_bench_fails_as_a_whole_when_one_rank_dies_or_hangs(mode):
     wall = time.time() - t0
     assert r.returncode != 0, "the job reported success although rank 1 was gone"
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "a bench line was printed by a job that lost a rank"
-    if mode == "HANG":
-        assert "made no progress" in r.stderr, r.stderr[-1500:]
+    # (HANG: whichever fires first ends the job -- rank 0's barrier timing out, here after 8 s, or rank 1's watchdog after 10 s with
+    # "made no progress" on stderr; the watchdog's own exit is pinned by tests/test_host_side.py without a launcher in the way)
     # start-up (two imports of torch, engines, replay prefill) + at most timeout / watchdog + the launcher's clean-up
     assert wall < 120.0, wall
 
