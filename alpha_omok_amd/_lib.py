@@ -18,7 +18,7 @@ class AoConfig(C.Structure):
     _fields_ = [("board", C.c_int32), ("win_mark", C.c_int32), ("sims", C.c_int32),
                 ("inplanes", C.c_int32), ("games", C.c_int32), ("noise", C.c_int32),
                 ("node_cap", C.c_int32), ("device", C.c_int32), ("c_puct", C.c_double),
-                ("alpha", C.c_double)]
+                ("alpha", C.c_double), ("arena_fraction", C.c_double)]
 
 
 class AoRolloutConfig(C.Structure):
@@ -145,7 +145,7 @@ def load(build_if_missing=True):
             raise RuntimeError("libomok_hip.so does not export %s (stale build?)" % name)
         fn.restype = res
         fn.argtypes = args
-    if lib.ao_abi_version() != 1:
+    if lib.ao_abi_version() != 2:
         raise RuntimeError("libomok_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -196,6 +196,8 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return e->fail("no HIP device available");
     if (c.device < 0 || c.device >= ndev) return e->fail("device ordinal out of range");
     AO_HIP(e, hipSetDevice(c.device));
+    if (c.arena_fraction < 0.0 || c.arena_fraction > 0.90) return e->fail("arena_fraction must be in (0, 0.90] (0 = the default 0.40)");
+    const double arena_fraction = c.arena_fraction > 0.0 ? c.arena_fraction : 0.40;
     if (c.node_cap == 0) {
         // Default arena: 16 x (sims + 1) expanded nodes per game where the part is large enough, never less than
         // 4 x (sims + 1). Re-rooting keeps the chosen child's subtree, so with a share f of the root's visits in that
@@ -213,7 +215,7 @@ static int create_impl(ao_engine* e, const ao_config* cfg) {
         size_t free_b = 0, total_b = 0;
         long cap = 16L * (c.sims + 1);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            cap = std::min<long>(cap, static_cast<long>(0.40 * static_cast<double>(total_b) / (2.0 * c.games * node_bytes)));
+            cap = std::min<long>(cap, static_cast<long>(arena_fraction * static_cast<double>(total_b) / (2.0 * c.games * node_bytes)));
         cap = std::max<long>(cap, 4L * (c.sims + 1));
         c.node_cap = static_cast<int32_t>(std::min<long>(cap, 15000));
     } else if (c.node_cap < 0) {

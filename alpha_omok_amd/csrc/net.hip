@@ -864,10 +864,11 @@ int ao_net_create(int n_block, int inplanes, int planes, int board, int device, 
     auto bad = [&](const char* m) { g_net_create_error = m; return 1; };
     if (n_block < 0 || n_block > 64) return bad("n_block out of range");
     if (inplanes < 1 || inplanes > 12) return bad("inplanes must be in 1..12");
-    // 32 .. 128 planes: every path (128: the split-fp16 MFMA kernels). 160 .. 256: the row-chunked fp32-MFMA layer kernels
-    // (mode 4) for every batch size, a group's output channels split over two workgroups (k_layer16) -- model.py:76-85
-    // takes any `planes`; wider or odd widths stay with the caller's torch module (alpha_omok_amd/evaluator.py)
-    if (planes < 32 || planes > 256 || planes % 32) return bad("planes must be a multiple of 32 in 32 .. 256");
+    // 32 .. 128 planes: every path (128: the split-fp16 MFMA kernels). 160 .. 512: the row-chunked fp32-MFMA layer kernels
+    // (mode 4) for every batch size, a group's output channels split over two .. four workgroups (k_layer16) -- model.py:76-85
+    // takes any `planes`: other widths reach this call zero-padded to the next multiple of 32 (pvnet.pad_state_dict); beyond 512
+    // the caller's torch module evaluates (alpha_omok_amd/evaluator.py: a RuntimeWarning, or an error with strict_native)
+    if (planes < 32 || planes > 512 || planes % 32) return bad("planes must be a multiple of 32 in 32 .. 512");
     if (board < 3 || board > ao::kMaxBoard) return bad("board must be in 3..15");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad("no HIP device available");

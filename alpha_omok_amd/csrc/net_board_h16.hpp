@@ -32,7 +32,8 @@
 #pragma once
 
 // Timing knock-outs (-DAO_BKO=n, WRONG RESULTS, experiment builds only: AO_BUILD_TAG): 1 no DPP shifts (every tap column reads the
-// unshifted fragment), 3 no epilogue (no LDS writes), 4 the weights of a layer's block 0 only, 5 no board load. (Measured on the first,
+// unshifted fragment), 3 no epilogue (no LDS writes), 4 the weights of a layer's block 0 only, 5 no board load, 6 no residual (the ResBlock
+// input is not kept: prices the 60 registers it occupies and the scratch traffic of what spills; round 6). (1 - 5 measured on the first,
 // slab-streamed form of the kernel: profiles/r5k_boardh_knockouts.txt.)
 #ifndef AO_BKO
 #define AO_BKO 0
@@ -73,6 +74,7 @@ template <int BW, int IN, bool W16>
 __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
     static_assert(BW >= 10 && BW <= 15, "rows are padded to 16 cells and need at least one zero pad");
     __shared__ uint8_t s_pl[256];                  // IN 2: the board's plane bytes
+    __shared__ __attribute__((aligned(16))) float s_w3[384];
     constexpr int A = BW * BW;
     constexpr int NCI = 4, NT = 8;                 // 128 channels: four 32-channel blocks, eight 16-channel cout tiles
     constexpr int NFR = BW * NCI * 2;              // 1 KB fragments of the board
@@ -89,12 +91,9 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
     // the lane's 8-byte slot inside output fragment (row, tile >> 1, half): cout quad q = kq -> k-octet (tile & 1) * 2 + (kq >> 1)
     const int out_off = (((tile & 1) * 2 + (kq >> 1)) * 16 + n) * 16 + (kq & 1) * 8;
     float peak = 0.f;
-    // the head convs' weights of this lane's four couts (tile * 16 + kq * 4 + c), three heads
-    float w3r[3][4];
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w3r[h][c] = a.w3[h * 128 + tile * 16 + kq * 4 + c];
+    // the head convs' weights [3][128] in LDS: read in the last epilogue only (held in registers from here they cost 12 live VGPRs
+    // through every layer of a kernel that has none to spare)
+    if (threadIdx.x < 384) s_w3[threadIdx.x] = a.w3[threadIdx.x];
     // Which board a workgroup carries: the 16 boards of a GROUP share every 128-byte line of the group layout (a board's share of a
     // line is 16 bytes), so they go to 16 workgroups of ONE XCD at the same time -- workgroups are dealt round robin over the 8 XCDs:
     // virtual index v = round * gridDim + blockIdx -> XCD x = v % 8, position j = v / 8: group (j / 16) * 8 + x, slot j % 16. A line
@@ -166,7 +165,7 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
                         const float v = n < BW ? fminf(fmaxf(f[k], 0.f), 65504.f) : 0.f;
                         hh[k] = static_cast<_Float16>(v);
                         hl[k] = static_cast<_Float16>(v - static_cast<float>(hh[k]));
-                        xres[y][k] = static_cast<float>(hh[k]) + static_cast<float>(hl[k]);   // (what the gather of IN 1 reconstructs)
+                        if (AO_BKO != 6) xres[y][k] = static_cast<float>(hh[k]) + static_cast<float>(hl[k]);   // (what the gather of IN 1 reconstructs)
                     }
                     char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
                     *reinterpret_cast<half4*>(frag + out_off) = hh;
@@ -190,7 +189,7 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
 #pragma unroll
             for (int y = 0; y < BW; ++y) {   // x = xh + xl of conv1's output, this wave's cout tile in D-operand order
                 xres[y] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n < BW && AO_BKO != 5) {
+                if (n < BW && AO_BKO != 5 && AO_BKO != 6) {
                     const char* p = gact + (static_cast<size_t>(y * BW + n) * NCI + (tile >> 1)) * 2048u + (((tile & 1) * 2 + (kq >> 1)) * 16 + bslot) * 16 + (kq & 1) * 8;
                     const half4 hh = *reinterpret_cast<const half4*>(p), hl = *reinterpret_cast<const half4*>(p + 1024);
 #pragma unroll
@@ -269,7 +268,7 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
 #pragma unroll
             for (int y = 0; y < BW; ++y) {
                 float f[4] = {fmaf(acc[y][0], sc.x, sh.x), fmaf(acc[y][1], sc.y, sh.y), fmaf(acc[y][2], sc.z, sh.z), fmaf(acc[y][3], sc.w, sh.w)};
-                if (second) {
+                if (second && AO_BKO != 6) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) f[c] += xres[y][c];
                 }
@@ -290,9 +289,11 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
                     float hs[3];
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
-                        float t = 0.f;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) t = fmaf(v[c], w3r[h][c], t);
+                        const float4 w4 = *reinterpret_cast<const float4*>(s_w3 + h * 128 + tile * 16 + kq * 4);
+                        float t = fmaf(v[0], w4.x, 0.f);
+                        t = fmaf(v[1], w4.y, t);
+                        t = fmaf(v[2], w4.z, t);
+                        t = fmaf(v[3], w4.w, t);
                         t += __shfl_xor(t, 16);
                         t += __shfl_xor(t, 32);
                         hs[h] = t;
@@ -307,7 +308,7 @@ __device__ __forceinline__ void boardh_body(const BoardHArgs& a) {
                 char* frag = reinterpret_cast<char*>(s_x + ((y * NCI + (tile >> 1)) * 2) * 64);
                 *reinterpret_cast<half4*>(frag + out_off) = hh;
                 *reinterpret_cast<half4*>(frag + 1024 + out_off) = hl;
-                if (second) xres[y] = f32x4{v[0], v[1], v[2], v[3]};   // the next block's input
+                if (second && AO_BKO != 6) xres[y] = f32x4{v[0], v[1], v[2], v[3]};   // the next block's input
             }
             __syncthreads();
             if (last) {

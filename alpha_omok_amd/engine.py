@@ -148,11 +148,11 @@ class Engine:
     """G concurrent games: SoA search trees in HBM + the tree kernels (see include/omok_hip.h)."""
 
     def __init__(self, board_size, num_mcts, inplanes=5, games=1, noise=True, device=0, node_cap=0,
-                 c_puct=0.0, alpha=0.0, win_mark=0):
+                 c_puct=0.0, alpha=0.0, win_mark=0, arena_fraction=0.0):
         self._L = _lib.load()
         cfg = _lib.AoConfig(board=board_size, win_mark=win_mark, sims=num_mcts, inplanes=inplanes,
                             games=games, noise=1 if noise else 0, node_cap=node_cap, device=device,
-                            c_puct=c_puct, alpha=alpha)
+                            c_puct=c_puct, alpha=alpha, arena_fraction=arena_fraction)
         h = C.c_void_p()
         if self._L.ao_create(C.byref(cfg), C.byref(h)):
             raise EngineError("ao_create: " + self._L.ao_last_error(None).decode())

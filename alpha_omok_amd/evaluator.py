@@ -32,14 +32,14 @@ class Evaluator:
         if cfg is None or cfg[3] != board_size or cfg[1] != inplanes:
             return None
         if not pvnet.native_supported(cfg[2]):
-            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward covers up to 256 (other widths zero-padded to
+            # model.PVNet takes any `planes` (model.py:76-85); the hand-written forward covers up to 512 (other widths zero-padded to
             # the next multiple of 32, pvnet.pad_state_dict). Wider networks: INTEGRATION.md, "Network widths".
             if self.strict_native:
                 raise ValueError("PVNet with %d planes has no native MI355X forward (up to %d planes) and strict_native is set"
                                  % (cfg[2], pvnet.NATIVE_MAX_PLANES))
             if not self._warned_width:
                 import warnings
-                warnings.warn("PVNet with %d planes: the native MI355X forward covers up to 256 planes -- this network "
+                warnings.warn("PVNet with %d planes: the native MI355X forward covers up to 512 planes -- this network "
                               "is evaluated by its own torch module, one call per simulation on the whole leaf batch "
                               "(correct, but several times slower than the MFMA kernels)" % cfg[2], RuntimeWarning, stacklevel=3)
                 self._warned_width = True

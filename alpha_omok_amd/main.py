@@ -241,16 +241,12 @@ def _get_engine(games):
             _trim_base[1] += t
             _engine.close()
         _trim_seen[0] = 0
-        node_cap = NODE_CAP
-        if node_cap == 0 and games > MAX_CONCURRENT:
-            # more trees than the library's default arena rule plans for (40 % of the HBM for MAX_CONCURRENT-like counts): half of
-            # the HBM for them, at most 16 x (sims + 1) nodes each
-            import torch
-            total = torch.cuda.mem_get_info(Agent._device)[1]
-            A = BOARD_SIZE * BOARD_SIZE
-            rec = (25 * ((A + 15) // 16 * 16) + 80 + 127) // 128 * 128
-            node_cap = int(max(4 * (N_MCTS + 1), min(16 * (N_MCTS + 1), 0.5 * total / (2.0 * games * rec))))
-        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device, node_cap=node_cap)
+        # more trees than the library's default arena rule plans for (40 % of the HBM for MAX_CONCURRENT-like counts): half of the
+        # HBM for an over-subscribed engine's trees -- still the DEFAULT rule (ao_config.arena_fraction), so its clamps and its
+        # shrink-on-allocation-failure retry apply (round-5 advisor: an explicit node_cap bypassed both)
+        frac = 0.5 if (NODE_CAP == 0 and games > MAX_CONCURRENT) else 0.0
+        _engine = Engine(BOARD_SIZE, N_MCTS, IN_PLANES, games=games, noise=Agent.noise, device=Agent._device, node_cap=NODE_CAP,
+                         arena_fraction=frac)
     return _engine
 
 
@@ -1069,9 +1065,10 @@ if __name__ == '__main__':
     ap.add_argument('--train-steps', type=int, default=None, help='mini-batches per training pass (default: the reference\'s one per new sample)')
     ap.add_argument('--oversubscribe', type=float, default=None, help='game slots per row of the evaluation batch (1.25 with a trained network)')
     ap.add_argument('--overlap-train', action='store_true', help='train beside the next iteration\'s games (train_async)')
+    ap.add_argument('--fp16-grid-weights', action='store_true', help='keep the 3x3 conv weights on the fp16 grid: two-product split-fp16 kernels (configure)')
     a = ap.parse_args()
     parallel.init_from_env()
     GAMES_PER_ITER, TRAIN_STEPS = a.games_per_iter, a.train_steps
     configure(board_size=a.board, n_mcts=a.sims, n_blocks=a.blocks, device_replay=a.device_replay, oversubscribe=a.oversubscribe,
-              overlap_train=a.overlap_train)
+              overlap_train=a.overlap_train, fp16_grid_weights=a.fp16_grid_weights)
     run(a.iters, a.model, a.dataset, a.selfplay)

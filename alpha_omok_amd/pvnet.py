@@ -84,7 +84,7 @@ class PVNet(nn.Module):
         return net
 
 
-NATIVE_MAX_PLANES = 256
+NATIVE_MAX_PLANES = 512
 
 
 def native_supported(planes):
@@ -93,10 +93,10 @@ def native_supported(planes):
 
 
 def native_width(planes):
-    """The width the HIP forward runs a `planes`-wide network at: the next multiple of 32 (at most 256), or `planes` itself when
-    the native kernels cannot take it (wider than 256: the caller's torch module evaluates it)."""
+    """The width the HIP forward runs a `planes`-wide network at: the next multiple of 32 (at most NATIVE_MAX_PLANES = 512), or
+    `planes` itself when the native kernels cannot take it (wider: the caller's torch module evaluates it)."""
     width = (int(planes) + 31) // 32 * 32
-    return width if 32 <= width <= 256 else int(planes)
+    return width if 32 <= width <= NATIVE_MAX_PLANES else int(planes)
 
 
 def pad_state_dict(state_dict, width):

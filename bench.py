@@ -427,12 +427,8 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
     A_ = B * B
 
     def run(games, row_cap):
-        node_cap = 0
-        if games > G:   # more trees than the default arena rule plans for: half of the HBM for them, at most 16 x (sims + 1) nodes each
-            total = torch.cuda.mem_get_info(local)[1]
-            rec = (25 * ((A_ + 15) // 16 * 16) + 80 + 127) // 128 * 128
-            node_cap = int(max(4 * (S + 1), min(16 * (S + 1), 0.5 * total / (2.0 * games * rec))))
-        eng = Engine(B, S, 5, games=games, noise=True, device=local, node_cap=node_cap)
+        # more trees than the default arena rule plans for: half of the HBM for them (ao_config.arena_fraction; at most 16 x (sims + 1) nodes each)
+        eng = Engine(B, S, 5, games=games, noise=True, device=local, arena_fraction=0.5 if games > G else 0.0)
         if row_cap:
             eng.set_row_cap(row_cap)
         eng.seed_all(np.arange(7 * G, 7 * G + games, dtype=np.uint32))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AO_ABI_VERSION 1
+#define AO_ABI_VERSION 2   /* 2: ao_config.arena_fraction (round 6) */
 
 typedef struct ao_engine ao_engine; /* search engine: G games                       */
 typedef struct ao_net ao_net;       /* policy/value ResNet (model.py PVNet) weights  */
@@ -43,6 +43,9 @@ typedef struct ao_config {
     int32_t device;     /* HIP device ordinal                                                  */
     double  c_puct;     /* 0 = 5 (agents.py:48)                                                */
     double  alpha;      /* 0 = 10/board^2 (agents.py:47)                                       */
+    double  arena_fraction; /* node_cap == 0 only: the share of the device's TOTAL memory the default rule may give the two
+                           arenas of all games; 0 = 0.40 (main.py's over-subscribed engines ask for 0.50); (0, 0.90]. The
+                           default path keeps its shrink-on-allocation-failure retry and its clamps (ABI version 2)   */
 } ao_config;
 
 /* root status reported by ao_set_root / ao_begin_move (agents.py:82-111) */

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libomok_hip.so does not export %s" % name
     assert set(_lib.SYMBOLS) == declared
-    assert lib.ao_abi_version() == 1
+    assert lib.ao_abi_version() == 2
     assert b"gfx950" in lib.ao_version()
 
 

@@ -301,11 +301,13 @@ def test_small_batch_row_kernel(nb, B, batch, seed, monkeypatch):
     net.close()
 
 
-@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 256, 40), (1, 5, 192, 700), (2, 15, 160, 24), (3, 9, 224, 1024), (1, 3, 256, 5)])
+@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 256, 40), (1, 5, 192, 700), (2, 15, 160, 24), (3, 9, 224, 1024), (1, 3, 256, 5),
+                                               (2, 9, 288, 40), (1, 9, 512, 600), (2, 15, 384, 20), (1, 7, 320, 1), (1, 3, 512, 3)])
 def test_wide_networks_run_on_the_fp32_layer_kernels(nb, B, planes, batch):
-    """model.PVNet takes any `planes` (model.py:76-85). 160 .. 256 planes (multiples of 32) run natively on the row-chunked
-    fp32-MFMA layer kernels for every batch size -- a group's output channels beyond 128 go to a second workgroup of k_layer16 --
-    whatever mode is asked for; checked against torch fp32, and through a fused search against the stepwise one."""
+    """model.PVNet takes any `planes` (model.py:76-85). 160 .. 512 planes (multiples of 32; 256 until round 6) run natively on the
+    row-chunked fp32-MFMA layer kernels for every batch size -- a group's output channels beyond 128 go to a second, third, fourth
+    workgroup of k_layer16 -- whatever mode is asked for; checked against torch fp32, and through a fused search against the
+    stepwise one."""
     import torch
     from alpha_omok_amd.engine import Engine
     from alpha_omok_amd.pvnet import PVNet
@@ -329,7 +331,17 @@ def test_wide_networks_run_on_the_fp32_layer_kernels(nb, B, planes, batch):
         a, b2 = Engine(B, S, 5, games=G, noise=True), Engine(B, S, 5, games=G, noise=True)
         seeds = np.arange(G, dtype=np.uint32) + 3
         a.seed_all(seeds); b2.seed_all(seeds)
-        pi, vis, pol = a.search(net, tau=1)
+        if planes > 256:
+            # ... and through the evaluator a drop-in caller goes through (agents.py:171-178): the module is exported, not called
+            import warnings
+            from alpha_omok_amd.evaluator import Evaluator
+            ev = Evaluator(0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                assert ev.native_net(ref, B, 5) is not None
+                pi, vis, pol = ev.search(a, ref, 1)
+        else:
+            pi, vis, pol = a.search(net, tau=1)
         planes_t = torch.zeros((G, 5, B, B), dtype=torch.float32, device="cuda")
         b2.begin_move()
         while b2.sims_left() > 0:
@@ -710,7 +722,7 @@ def test_board_resident_trunk_wide_boards_vs_torch_and_per_layer(nb, B, batch):
     net_l.close()
 
 
-@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 100, 300), (1, 7, 40, 33), (2, 9, 200, 64), (2, 15, 100, 70)])
+@pytest.mark.parametrize("nb,B,planes,batch", [(2, 9, 100, 300), (1, 7, 40, 33), (2, 9, 200, 64), (2, 15, 100, 70), (1, 9, 300, 48), (1, 5, 500, 9)])
 def test_widths_that_are_not_a_multiple_of_32_run_natively_zero_padded(nb, B, planes, batch):
     """model.PVNet takes any `planes` (model.py:76-85). Round 5: widths up to 256 that are not a multiple of 32 are exported
     zero-padded to the next multiple (pvnet.pad_state_dict) and run on the same MFMA kernels -- 100 planes on the split-fp16

@@ -477,7 +477,7 @@ def test_pad_state_dict_keeps_the_function():
     extra channels, zero columns / rows in the heads). torch on both: equal up to the order of summation."""
     import torch
     from alpha_omok_amd.pvnet import PVNet, native_width, pad_state_dict
-    assert [native_width(p) for p in (20, 32, 33, 100, 128, 130, 250, 256, 300)] == [32, 32, 64, 128, 128, 160, 256, 256, 300]
+    assert [native_width(p) for p in (20, 32, 33, 100, 128, 130, 250, 256, 300, 512, 513, 600)] == [32, 32, 64, 128, 128, 160, 256, 256, 320, 512, 513, 600]
     for nb, planes, B in ((2, 100, 9), (1, 40, 7), (3, 130, 5)):
         torch.manual_seed(planes)
         m = PVNet(nb, 5, planes, B)
@@ -503,14 +503,14 @@ def test_pad_state_dict_keeps_the_function():
 
 
 def test_wide_networks_take_the_module_path_loudly():
-    """model.PVNet takes any `planes` (model.py:76-85); the native forward stops at 256. A wider network -- multiples of 32 included
-    (round-5 advisor finding: 288 / 320 / 512 reached ao_net_create and raised) -- is evaluated by its own torch module after ONE
-    RuntimeWarning, or raises at once with strict_native. Decided before any GPU call."""
+    """model.PVNet takes any `planes` (model.py:76-85); the native forward stops at 512 (round 6; 256 before). A wider network --
+    multiples of 32 included (round-5 advisor finding: 288 / 320 / 512 reached ao_net_create and raised when the limit was 256) -- is
+    evaluated by its own torch module after ONE RuntimeWarning, or raises at once with strict_native. Decided before any GPU call."""
     import warnings
     from alpha_omok_amd.evaluator import Evaluator
     from alpha_omok_amd.pvnet import PVNet, native_supported
-    assert [native_supported(p) for p in (1, 20, 256, 257, 288, 320, 512)] == [True, True, True, False, False, False, False]
-    for planes in (288, 300, 512):
+    assert [native_supported(p) for p in (1, 20, 256, 257, 288, 320, 512, 513, 544, 1024)] == [True, True, True, True, True, True, True, False, False, False]
+    for planes in (513, 544, 1024):
         ev = Evaluator(0)
         m = PVNet(1, 5, planes, 5)
         with warnings.catch_warnings(record=True) as w:
@@ -522,7 +522,7 @@ def test_wide_networks_take_the_module_path_loudly():
         with pytest.raises(ValueError, match="no native MI355X forward"):
             ev.native_net(m, 5, 5)
     # another board / plane count than the engine's: not a PVNet for this engine, no warning
-    assert Evaluator(0).native_net(PVNet(1, 5, 512, 5), 9, 5) is None
+    assert Evaluator(0).native_net(PVNet(1, 5, 544, 5), 9, 5) is None
 
 
 def test_lazy_samples_unpack_like_the_tuples_they_stand_for():
