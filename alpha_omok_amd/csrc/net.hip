@@ -196,8 +196,9 @@ static bool board_resident(const ao_net* n, int boards) {
 static bool h16_supported(const ao_net* n) {
     return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
-// the two-product kernels run (the resident trunk in its default activation format, k_layer16h's trunk layers, k_boardh; every
-// other split-fp16 kernel keeps its three products -- on such weights the same bits)
+// the two-product kernels run (the resident trunk in its default activation format, the trunk layers of k_layer16h / k_layer16hk<B, 4> /
+// k_row16hk, k_boardh; what is left -- conv1 of the per-layer paths, the per-board path -- keeps its three products: on such weights
+// the same bits)
 static bool two_products(const ao_net* n) { return n->w16 && n->products_req != 3; }
 
 namespace ao {
@@ -531,6 +532,12 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
             a.live = live; a.row_cap = row_cap;
             const dim3 grid(rowk ? (groups + 7) / 8 * 8 * 4 * n->B : (groups + 7) / 8 * 8 * ks), block(512);
             const int idx = n->timing ? timer_begin(n, s) : 0;
+            if (two_products(n) && (rowk || ks == 4)) {
+                if (rowk) NET_HIP(n, ao::launch_row16hk_w16(n->device, n->B, grid, s, a));
+                else NET_HIP(n, ao::launch_layer16hk_w16(n->device, n->B, grid, s, a));
+                if (n->timing) timer_end(n, idx, s);
+                return 0;
+            }
             if (rowk) {
                 switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
@@ -1238,13 +1245,16 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
         f = conv;
     } else if (group == 16 && mode == 5 && !layers_only(n) && n->B >= 4 && n->B <= 9 && (boards + 15) / 16 >= n->rowk_min &&
                (boards + 15) / 16 <= n->rowk_max) {
-        nm = "k_row16hk<" + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): one workgroup per "
+        nm = std::string(two_products(n) ? "k_row16hk_w16<" : "k_row16hk<") + bw + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (" +
+             (two_products(n) ? "2 products: the conv weights are fp16 numbers" : "3 products") + ", fp32 accumulate): one workgroup per "
              "16-board group x output row x cout pair, waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;
     } else if (group == 16 && mode == 5 && !layers_only(n) && n->B >= 4 && n->B <= 9 && (boards + 15) / 16 >= n->ksplit_min &&
                (boards + 15) / 16 <= std::max(n->ksplit_max, n->ksplit_max2)) {
         const bool four = (boards + 15) / 16 <= n->ksplit_max;
-        nm = "k_layer16hk<" + bw + (four ? ", 4" : ", 2") + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (3 products, fp32 accumulate): "
+        const bool two = two_products(n) && four;
+        nm = std::string(two ? "k_layer16hk_w16<" : "k_layer16hk<") + bw + (four ? ", 4" : ", 2") + "> (one 3x3 conv per launch as split-fp16 MFMA 16x16x32 (" +
+             (two ? "2 products: the conv weights are fp16 numbers" : "3 products") + ", fp32 accumulate): "
              "a 16-board group split over " + (four ? "four workgroups by cout pairs" : "two workgroups by cout quads") +
              ", waves split the contraction by input block, partial tiles exchanged through LDS)";
         f = conv;

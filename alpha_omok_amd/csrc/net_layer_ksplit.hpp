@@ -34,8 +34,10 @@
 
 namespace ao {
 
-template <int BW, int KS>
-__global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
+// W16: the conv weights are fp16 numbers (zero low halves): two products per multiply-add, no low weight fragments -- see
+// TrunkHLayerFn in net_trunk_h16.hpp. The resident weights of a wave are then 36 registers instead of 72.
+template <int BW, int KS, bool W16>
+__device__ __forceinline__ void layer16hk_body(const LayerHArgs& a) {
     static_assert(KS == 2 || KS == 4, "workgroups per group");
     constexpr int TW = 8 / KS;               // cout tiles of a workgroup
     constexpr int CB = 4 / KS;               // 32-channel input blocks of a wave
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
         for (int t = 0; t < 9; ++t) {
             const int ub = ((t * NCI + kp) * NT + tile) * 1024;
             W[0][t] = buf_ld_h8(rs_wh, lane16, ub);
-            W[1][t] = buf_ld_h8(rs_wl, lane16, ub);
+            if (!W16) W[1][t] = buf_ld_h8(rs_wl, lane16, ub);
         }
     }
     auto load_slab = [&](int sl, half8 (&Wd)[2][CB == 1 ? 1 : 3]) {
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
             for (int dx = 0; dx < 3; ++dx) {
                 const int ub = (((dy * 3 + dx) * NCI + c) * NT + tile) * 1024;
                 Wd[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
-                Wd[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+                if (!W16) Wd[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
             }
         }
     };
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             asm volatile("" ::"v"(W[0][t]));
-            asm volatile("" ::"v"(W[1][t]));
+            if (!W16) asm volatile("" ::"v"(W[1][t]));
         }
     }
 
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
                 }
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr) {
+                    if (W16 && pr == 1) continue;   // (wl == 0)
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const int yo = s + 1 - dy;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
                         }
 #pragma unroll
                         for (int pr = 0; pr < 3; ++pr) {
+                    if (W16 && pr == 1) continue;   // (wl == 0)
 #pragma unroll
                             for (int dx = 0; dx < 3; ++dx) {
                                 const int i = xi - dx + 1;
@@ -312,6 +316,15 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
     if (peak > 65504.f) atomicOr(L.ovf, 1);
 }
 
+template <int BW, int KS>
+__global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
+    layer16hk_body<BW, KS, false>(a);
+}
+template <int BW, int KS>
+__global__ __launch_bounds__(512, 1) void k_layer16hk_w16(LayerHArgs a) {   // launched from net_w16.hip
+    layer16hk_body<BW, KS, true>(a);
+}
+
 
 // k_row16hk: the same decomposition for SMALL and medium-small batches, where even four workgroups per group leave most of
 // the chip idle: workgroup (group, output row y, cout pair j) -- 36 workgroups per 9x9 group, all of a group on one XCD. Its
@@ -322,8 +335,8 @@ __global__ __launch_bounds__(512, 1) void k_layer16hk(LayerHArgs a) {
 // what it buys is parallelism (16 groups: 576 workgroups, two per CU, instead of k_layer16hk's 64 or k_layer16h's 144). Per
 // accumulator the order of the MFMAs (input rows y-1, y, y+1; inside a row: cell, product, tap column) and the order of the
 // exchange (input blocks 0 .. 3) are k_layer16hk's: the results are the same bits.
-template <int BW>
-__global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
+template <int BW, bool W16>
+__device__ __forceinline__ void row16hk_body(const LayerHArgs& a) {
     constexpr int KS = 4, TW = 2;
     constexpr int NC32 = 4, NCI = 4, NT = 8;
     constexpr int A = BW * BW;
@@ -381,13 +394,13 @@ __global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
         for (int dx = 0; dx < 3; ++dx) {
             const int ub = (((DY * 3 + dx) * NCI + kp) * NT + tile) * 1024;
             W[0][dx] = buf_ld_h8(rs_wh, lane16, ub);
-            W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
+            if (!W16) W[1][dx] = buf_ld_h8(rs_wl, lane16, ub);
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {   // (a use the wait-count pass can see: k_layer16hk)
             asm volatile("" ::"v"(W[0][dx]));
-            asm volatile("" ::"v"(W[1][dx]));
+            if (!W16) asm volatile("" ::"v"(W[1][dx]));
         }
         half8 xh = ldx(0, 0), xl = ldx(0, 1);
 #pragma unroll
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
             }
 #pragma unroll
             for (int pr = 0; pr < 3; ++pr) {
+                    if (W16 && pr == 1) continue;   // (wl == 0)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int i = xi - dx + 1;
@@ -467,6 +481,15 @@ __global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
         buf_st_h4(hl, rs_dst, out_voff, ob + 1024);
     }
     if (peak > 65504.f) atomicOr(L.ovf, 1);
+}
+
+template <int BW>
+__global__ __launch_bounds__(512, 2) void k_row16hk(LayerHArgs a) {
+    row16hk_body<BW, false>(a);
+}
+template <int BW>
+__global__ __launch_bounds__(512, 2) void k_row16hk_w16(LayerHArgs a) {   // launched from net_w16.hip
+    row16hk_body<BW, true>(a);
 }
 
 }  // namespace ao

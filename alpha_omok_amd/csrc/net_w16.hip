@@ -15,6 +15,7 @@
 #include "net_common.hpp"
 #include "net_trunk_f32.hpp"
 #include "net_trunk_h16.hpp"
+#include "net_layer_ksplit.hpp"
 #include "net_board_h16.hpp"
 #include "net_w16.hpp"
 
@@ -23,7 +24,7 @@ namespace ao {
 namespace {
 constexpr int kDev = 16;
 // dynamic-LDS attribute set once per (device, kernel)
-bool g_attr_trunk[kDev][16][2], g_attr_layer[kDev][16][2], g_attr_board[kDev][16][2];
+bool g_attr_trunk[kDev][16][2], g_attr_layer[kDev][16][2], g_attr_board[kDev][16][2], g_attr_ksplit[kDev][16][2];
 
 template <typename K>
 hipError_t set_lds(bool* done, K kernel, size_t lds) {
@@ -77,6 +78,40 @@ hipError_t launch_layer16h_w16(int device, int B, int xt, dim3 grid, hipStream_t
         AO_BW_CASE(10) AO_BW_CASE(11) AO_BW_CASE(12) AO_BW_CASE(13) AO_BW_CASE(14) AO_BW_CASE(15)
 #undef AO_BW_CASE
 #undef AO_LAYERH_LAUNCH
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_layer16hk_w16(int device, int B, dim3 grid, hipStream_t s, const LayerHArgs& a) {
+    if (device < 0 || device >= kDev) return hipErrorInvalidDevice;
+    switch (B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W: {                                                                                                          \
+        constexpr size_t lds_ = static_cast<size_t>(2) * W * 8 * 1024;                                                 \
+        const hipError_t st = set_lds(&g_attr_ksplit[device][W][0], &k_layer16hk_w16<W, 4>, lds_);                     \
+        if (st != hipSuccess) return st;                                                                               \
+        hipLaunchKernelGGL((k_layer16hk_w16<W, 4>), grid, dim3(512), lds_, s, a);                                      \
+    } break;
+        AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+#undef AO_BW_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_row16hk_w16(int device, int B, dim3 grid, hipStream_t s, const LayerHArgs& a) {
+    if (device < 0 || device >= kDev) return hipErrorInvalidDevice;
+    switch (B) {
+#define AO_BW_CASE(W)                                                                                                  \
+    case W: {                                                                                                          \
+        constexpr size_t lds_ = static_cast<size_t>(W) * 8 * 1024;                                                     \
+        const hipError_t st = set_lds(&g_attr_ksplit[device][W][1], &k_row16hk_w16<W>, lds_);                          \
+        if (st != hipSuccess) return st;                                                                               \
+        hipLaunchKernelGGL((k_row16hk_w16<W>), grid, dim3(512), lds_, s, a);                                           \
+    } break;
+        AO_BW_CASE(4) AO_BW_CASE(5) AO_BW_CASE(6) AO_BW_CASE(7) AO_BW_CASE(8) AO_BW_CASE(9)
+#undef AO_BW_CASE
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

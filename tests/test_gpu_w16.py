@@ -5,7 +5,8 @@ fp32 accumulate. When every conv weight (times its layer's power of two) IS an f
 exact zeros: the library notices at ao_net_finalize and plans kernels that leave it out. What must hold:
   * which networks qualify is decided by the weights alone (arbitrary fp32 weights: three products, as ever);
   * on qualifying weights the two-product kernels return the SAME BITS as the three-product kernels, in every kernel family that
-    has a two-product form (resident trunk on float planes and on the engine's bit planes, per-layer kernel, board-resident trunk);
+    has a two-product form (resident trunk on float planes and on the engine's bit planes, the three per-layer kernels, the
+    board-resident trunk);
   * and they are the fp32-equivalent contraction: within 1e-5 of torch fp32 on the same weights (the repo-wide contract is 1e-4);
   * training with configure(fp16_grid_weights=True) keeps the conv weights there, so the searches of a training run stay on two
     products, and the checkpoint is a plain fp32 state_dict.
@@ -41,6 +42,10 @@ CASES = [
     (2, 9, 1500, 6, "k_layer16h_w16<9>"),            # one launch per conv (mode 6: the per-layer family for every batch size)
     (2, 9, 1500, 0, "k_layer16h_w16<9>"),            # ... and as planned for a medium batch
     (1, 5, 400, 6, "k_layer16h_w16<5>"),
+    (2, 9, 900, 0, "k_layer16hk_w16<9, 4>"),         # 48 .. 64 groups: a group split over four workgroups by cout pairs
+    (1, 7, 1024, 0, "k_layer16hk_w16<7, 4>"),
+    (2, 9, 300, 0, "k_row16hk_w16<9>"),              # below 48 groups: one workgroup per group x output row x cout pair
+    (1, 6, 500, 0, "k_row16hk_w16<6>"),
     (2, 15, 96, 0, "k_boardh_w16<15, 1>"),           # wide boards: one board per workgroup, resident in LDS
     (1, 11, 130, 0, "k_boardh_w16<11, 1>"),
     (2, 15, 40, 0, "k_layer16h_w16<15>"),            # few wide boards: the per-layer kernel on column tiles
