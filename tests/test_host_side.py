@@ -824,3 +824,94 @@ def test_a_dead_or_hung_rank_fails_every_rank_quickly(tmp_path, mode):
     if mode == "hang":
         assert "made no progress" in outs[1][1]
     assert wall < 60.0, wall
+
+
+def _cpu_samples(rs, n, B=9):
+    return [((rs.rand(5, B, B) < 0.3).astype(np.float64), rs.dirichlet(np.ones(B * B)), float(rs.choice([-1, 0, 1]))) for _ in range(n)]
+
+
+def test_fp16_grid_training_on_cpu_keeps_conv_weights_on_the_grid_and_masters_off_it():
+    """configure(fp16_grid_weights=True) (round 6: networks whose conv weights are fp16 numbers run on the two-product kernels):
+    host logic only -- torch on CPU. After a pass every 3x3 conv weight of the module is an fp16 number, the fp32 master copies Adam
+    moves are not, everything else trains as ever, the state_dict is plain fp32, load_data re-synchronises the masters, and turning
+    the switch off drops them."""
+    import torch
+    from alpha_omok_amd import main
+    from alpha_omok_amd.pvnet import PVNet
+    torch.manual_seed(11)
+    try:
+        main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9), fp16_grid_weights=True,
+                       overlap_train=False, carry_over=False, device_replay=False)
+        model = main.Agent.model
+        convs = [p for p in model.parameters() if p.dim() == 4 and p.shape[2] == 3]
+        assert len(convs) == 3 and len(main._grid_masters) == 3
+        for p in convs:
+            assert torch.equal(p.detach().half().float(), p.detach())               # projected at configure()
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        rs = np.random.RandomState(3)
+        random.seed(9)
+        main.cur_memory.clear(); main.rep_memory.clear()
+        main.cur_memory.extend(_cpu_samples(rs, 3))
+        main.rep_memory.extend(_cpu_samples(rs, 200))
+        main.step = 0
+        losses = main.train(1, 1)
+        assert len(losses) == 3 and main.step == 3 and all(np.isfinite(l).all() for l in losses)
+        for p in convs:
+            assert torch.equal(p.detach().half().float(), p.detach())
+        assert all(not torch.equal(m.half().float(), m) for _, m in main._grid_masters)    # the masters are ordinary fp32
+        assert all(not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters())
+        assert all(v.dtype == torch.float32 for v in model.state_dict().values() if v.is_floating_point())
+        # the module's conv weights ARE the rounding of the masters
+        for p, m in main._grid_masters:
+            assert torch.equal(p.detach(), m.half().float())
+    finally:
+        main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9), fp16_grid_weights=False)
+    assert main._grid_masters == [] and main.FP16_GRID is False
+
+
+def _nonfinite_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from alpha_omok_amd import main, parallel
+    from alpha_omok_amd.pvnet import PVNet
+    parallel.init_from_env("gloo", pin=False)
+    torch.manual_seed(50 + rank)
+    main.configure(board_size=9, n_blocks=1, out_planes=32, seed=4, model=PVNet(1, 5, 32, 9), fp16_grid_weights=False)
+    rs = np.random.RandomState(100 + rank)
+    random.seed(200 + rank)
+    main.cur_memory.clear(); main.rep_memory.clear()
+    main.cur_memory.extend(_cpu_samples(rs, 2))
+    rep = _cpu_samples(rs, 64)
+    if rank == 1:                                         # ONE rank's shard is poisoned: every batch it draws has an infinite target
+        rep = [(s, p, float("inf")) for s, p, _ in rep]
+    main.rep_memory.extend(rep)
+    main.step = 0
+    main.skipped_steps = 0
+    w0 = {k: v.clone() for k, v in main.Agent.model.state_dict().items()}
+    losses = main.train(1, 1)
+    sd = {k: v.clone() for k, v in main.Agent.model.state_dict().items()}
+    torch.save(dict(sd=sd, w0=w0, skipped=main.skipped_steps, step=main.step, n_losses=len(losses)), out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_a_non_finite_gradient_on_one_rank_is_dropped_on_every_rank(tmp_path):
+    """main.train_batch's guard (round-5 advisor: it used to synchronise the host per step and to apply with one process only, so
+    multi-rank training wrote NaN into the weights as the reference would, main.py:296-305): after the gradient all-reduce every rank
+    holds the same -- non-finite -- gradient, zeroes it on the device and counts the mini-batch. Weights finite and bit-identical on
+    both ranks, both counted every step of the pass, and with zero gradients from step one Adam leaves the parameters where they were."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 29500 + random.randint(0, 2000)
+    out = str(tmp_path / "nf%d.pt")
+    mp.spawn(_nonfinite_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0["step"] == r1["step"] == 2 and r0["skipped"] == r1["skipped"] == 2
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+        if r0["sd"][k].is_floating_point():
+            assert torch.isfinite(r0["sd"][k]).all(), k
+    params = [k for k in r0["sd"] if "running_" not in k and "num_batches" not in k]
+    assert all(torch.equal(r0["sd"][k], r0["w0"][k]) for k in params)       # (rank 0's initial weights: configure() broadcast them)
