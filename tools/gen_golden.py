@@ -687,7 +687,8 @@ def gv14():
     """The reference's searches with the REAL network end to end (torch CPU, one thread): what `north_star`'s "visit counts and
     chosen moves bit-exact" has to be measured against once the evaluations come from the native MI355X forward instead of a
     replay (tests/test_gpu_realnet_drift.py). Visits / actions / stream positions only -- no recorded evaluations: 3 seeds x 6
-    plies with the random-init 4-block network of gv6 (torch.manual_seed(0)), 2 seeds x 6 plies with the trained 2-block fixture."""
+    plies with the random-init 4-block network of gv6 (torch.manual_seed(0)), 2 seeds x 6 plies with the trained 2-block fixture, and one 15x15 game
+    of 3 plies at 200 simulations with a random-init 10-block network (configs[4]'s shape)."""
     sys.path.insert(0, os.path.join(REPO, "tools"))
     from make_trained_fixture import load
     cases = []
@@ -705,6 +706,13 @@ def gv14():
         recs, win = _play(9, 400, 0, seed, 6, model=tnet)
         cases.append(((9, 400, -2, seed, 6, 6, 1), recs, win))
         print("  gv14 trained seed", seed, [r["action"] for r in recs])
+    # BASELINE configs[4]'s shape: 15x15, the reference's default 10 blocks (torch.manual_seed(1) init), 200 simulations, 3 plies
+    torch.manual_seed(1)
+    wnet = ref_model.PVNet(10, 5, 128, 15)
+    wnet.eval()
+    recs, win = _play(15, 200, 0, 5, 3, model=wnet)
+    cases.append(((15, 200, -3, 5, 3, 6, 1), recs, win))
+    print("  gv14 15x15 10-block seed 5", [r["action"] for r in recs])
     out = _pack(cases)
     for k in [k for k in out if k.split("_", 1)[-1] in ("w", "q", "policy", "pi", "order")]:
         del out[k]

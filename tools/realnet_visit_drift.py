@@ -7,7 +7,8 @@ torch's; PUCT compares q + u in float64 and takes an exact arg-max, so two evalu
 nearly equal children differently, and from that simulation on the two searches are different (equally valid) searches of the
 same position. This script measures how soon that happens: the reference's own torch-CPU searches are recorded in
 tests/golden/gv14_realnet_visits.npz (tools/gen_golden.py gv14: 3 seeds x 6 plies with the random-init 4-block network of gv6,
-2 seeds x 6 plies with the trained 2-block fixture; 9x9, 400 simulations, np.random.seed(seed) before the game), and the engine
+2 seeds x 6 plies with the trained 2-block fixture -- 9x9, 400 simulations -- and 3 plies of a 15x15 game with a random-init
+10-block network at 200 simulations; np.random.seed(seed) before the game), and the engine
 searches the same positions under the same seeds with its own forward. Runs ON THE GPU BOX:
 
     python tools/realnet_visit_drift.py            # JSON on stdout
@@ -27,12 +28,18 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, os.path.join(REPO, "tools"))
 
 
+NAMES = {-1: "random-init 4-block (gv6)", -2: "trained 2-block fixture", -3: "random-init 10-block 15x15 (configs[4]'s shape)"}
+
+
 def _network(kind):
     import torch
     from alpha_omok_amd.pvnet import PVNet
     if kind == -1:                                        # gv6's generator: torch's default init under manual_seed(0)
         torch.manual_seed(0)
         m = PVNet(4, 5, 128, 9)
+    elif kind == -3:
+        torch.manual_seed(1)
+        m = PVNet(10, 5, 128, 15)
     else:
         from make_trained_fixture import load
         m = PVNet(2, 5, 128, 9)
@@ -54,8 +61,7 @@ def measure(modes=(0, 2)):
             net = nets[(kind, mode)]
             eng = Engine(B, S, 5, games=1, noise=bool(noise))
             eng.seed(0, seed)
-            rec = dict(case=ci, network="random-init 4-block (gv6)" if kind == -1 else "trained 2-block fixture", seed=seed, net_mode=mode,
-                       plies=[], first_ply_parted=None)
+            rec = dict(case=ci, network=NAMES[kind], seed=seed, net_mode=mode, sims=S, recorded_plies=nrec, plies=[], first_ply_parted=None)
             for t in range(nrec):
                 root = [int(x) for x in g["c%d_root" % ci][t] if x >= 0]
                 eng.set_root(0, root)
