@@ -197,8 +197,8 @@ static bool h16_supported(const ao_net* n) {
     return n->planes == 128 && n->nb >= 1 && 1 + 2 * n->nb <= ao::kMaxTrunkLayers && n->nchq16 == 8;
 }
 // the two-product kernels run (the resident trunk in its default activation format, the trunk layers of k_layer16h / k_layer16hk<B, 4> /
-// k_row16hk, k_boardh; what is left -- conv1 of the per-layer paths, the per-board path -- keeps its three products: on such weights
-// the same bits)
+// k_row16hk, the per-board path's k_conv_cells_h, k_boardh; what is left -- conv1 of the per-layer and per-board paths, k_layer16hk<B, 2> --
+// keeps its three products: on such weights the same bits)
 static bool two_products(const ao_net* n) { return n->w16 && n->products_req != 3; }
 
 namespace ao {
@@ -414,6 +414,12 @@ int net_forward_il(ao_net* n, const float* in_il, int boards, float* policy, flo
                 switch (n->B) {
 #define AO_BW_CASE(W)                                                                                                  \
     case W:                                                                                                            \
+        if (two_products(n))                                                                                           \
+            hipLaunchKernelGGL((k_conv_cells_h_w16<W, 8>), grid_h, dim3(64 * 12), 0, s, reinterpret_cast<const float4*>(in),   \
+                               n->convh_wh[layer], reinterpret_cast<const float4*>(n->convh_sc[layer]),                \
+                               reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res), \
+                               reinterpret_cast<float4*>(out), cqi, n->planes, res ? 1 : 0, n->d_status, boards, bpw); \
+        else                                                                                                           \
         hipLaunchKernelGGL((k_conv_cells_h<W, 8>), grid_h, dim3(64 * 12), 0, s, reinterpret_cast<const float4*>(in), n->convh_wh[layer],   \
                            n->convh_wl[layer], reinterpret_cast<const float4*>(n->convh_sc[layer]),                    \
                            reinterpret_cast<const float4*>(n->conv_sh[layer]), reinterpret_cast<const float4*>(res),   \
@@ -1237,7 +1243,8 @@ static void dominant_name(const ao_net* n, int boards, int in_kind, std::string*
     std::string nm;
     double f;
     if (group == 1) {
-        nm = h16_supported(n) ? "k_conv_cells_h<" + bw + ", 8> (one 3x3 conv, per-board NHWC, board rows in LDS, split-fp16 MFMA 16x16x32)"
+        nm = h16_supported(n) ? std::string(two_products(n) ? "k_conv_cells_h_w16<" : "k_conv_cells_h<") + bw + ", 8> (one 3x3 conv, per-board NHWC, board rows in LDS, split-fp16 MFMA 16x16x32, " +
+                                    (two_products(n) ? "2 products: the conv weights are fp16 numbers)" : "3 products)")
                               : "k_conv_cells<" + bw + "> (one 3x3 conv, per-board NHWC, fp32 MFMA 16x16x4)";
         f = conv;
     } else if (group == 16 && mode == 4) {

@@ -192,7 +192,9 @@ __device__ __forceinline__ void conv_cells_tile(const float4* __restrict__ in, c
 // board and tile re-pulled the 72 KB of weights for every board: fine for a handful of games, L2-bound for a hundred.
 // s_red holds two buffers of (NW - 1) x 64 x 4 floats (alternating per board, so a wave may write the next board's partial
 // sums while wave 0 still adds up this board's).
-template <int BW, int NCQG, int NW>
+// W16: the conv weights are fp16 numbers (zero low halves, net_trunk_h16.hpp): no xh*wl product and -- what matters on this latency path -- half
+// the weight bytes through the CU.
+template <int BW, int NCQG, int NW, bool W16 = false>
 __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in, const uint4* __restrict__ wh, const uint4* __restrict__ wl,
                                                   const float4* __restrict__ scale, const float4* __restrict__ shift, const float4* res,
                                                   float4* out, int CQI, int COUT, int relu_res, int ct, int ctile, int board0, int nb,
@@ -220,7 +222,7 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
         for (int j = 0; j < NUH; ++j) {
             const size_t idx = (static_cast<size_t>(NUH * w3 + j) * nt + ct) * 64 + lane;   // unit = tap * NC32 + block
             whr[j] = __builtin_bit_cast(cc_half8, wh[idx]);
-            wlr[j] = __builtin_bit_cast(cc_half8, wl[idx]);
+            if (!W16) wlr[j] = __builtin_bit_cast(cc_half8, wl[idx]);
         }
     }
     float4 e_sc = make_float4(0.f, 0.f, 0.f, 0.f), e_sh = e_sc;
@@ -279,7 +281,7 @@ __device__ __forceinline__ void conv_cells_tile_h(const float4* __restrict__ in,
             // one accumulator chain per unit (up to four); hh, hl, lh of a unit go to the same chain
             f32x4& a = (j & 3) == 0 ? acc0 : (j & 3) == 1 ? acc1 : (j & 3) == 2 ? acc2 : acc3;
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xh, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j], xh, a, 0, 0, 0);
+            if (!W16) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlr[j], xh, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_f16(whr[j], xl, a, 0, 0, 0);
         }
         f32x4 acc;

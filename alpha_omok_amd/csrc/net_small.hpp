@@ -38,13 +38,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_conv_cells(const float4* __restr
 // The same tile on split-fp16 MFMAs (conv_cells_tile_h): 128-plane trunk layers, `bpw` boards per workgroup in turn. With
 // the activations coming from LDS the fp32 MFMAs of the nine waves (9 x 32 x 32 cycles on one CU's four matrix pipes)
 // were what was left of the launch; three 16-cycle fp16 MFMAs per 32-channel block replace eight 32-cycle fp32 ones.
-template <int BW, int NCQG>
-__global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
+template <int BW, int NCQG, bool W16>
+__device__ __forceinline__ void conv_cells_h_body(const float4* __restrict__ in, const uint4* __restrict__ wh,
                                                              const uint4* __restrict__ wl, const float4* __restrict__ scale,
                                                              const float4* __restrict__ shift, const float4* res, float4* out,
-                                                             int CQI, int COUT, int relu_res, int* ovf, int boards, int bpw) {
-    __shared__ float s_red[2 * 11 * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
+                                                             int CQI, int COUT, int relu_res, int* ovf, int boards, int bpw, float* s_red, float4* s_x) {
     // grid: output-channel tile fastest (workgroups go round robin over the 8 XCDs: XCD x only ever reads the weights of
     // tile x), then the cell tile, then the chunk of `bpw` boards this workgroup walks
     const int ntile = COUT >> 4;
@@ -53,9 +51,28 @@ __global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h(const float4* __res
     constexpr int NCT = (BW * BW + 15) / 16;
     const int b0 = (rest / NCT) * bpw;
     const int nb = boards - b0 < bpw ? boards - b0 : bpw;
-    conv_cells_tile_h<BW, NCQG, 12>(in, wh, wl, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, b0, nb, s_red, s_x, ovf);
+    conv_cells_tile_h<BW, NCQG, 12, W16>(in, wh, wl, scale, shift, res, out, CQI, COUT, relu_res, ct, rest % NCT, b0, nb, s_red, s_x, ovf);
 }
 
+template <int BW, int NCQG>
+__global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h(const float4* __restrict__ in, const uint4* __restrict__ wh,
+                                                             const uint4* __restrict__ wl, const float4* __restrict__ scale,
+                                                             const float4* __restrict__ shift, const float4* res, float4* out,
+                                                             int CQI, int COUT, int relu_res, int* ovf, int boards, int bpw) {
+    __shared__ float s_red[2 * 11 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
+    conv_cells_h_body<BW, NCQG, false>(in, wh, wl, scale, shift, res, out, CQI, COUT, relu_res, ovf, boards, bpw, s_red, s_x);
+}
+// the two-product form (fp16 weights): no low weight halves are read
+template <int BW, int NCQG>
+__global__ __launch_bounds__(64 * 12, 1) void k_conv_cells_h_w16(const float4* __restrict__ in, const uint4* __restrict__ wh,
+                                                                 const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                                                 const float4* res, float4* out, int CQI, int COUT, int relu_res, int* ovf,
+                                                                 int boards, int bpw) {
+    __shared__ float s_red[2 * 11 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float4 s_x[conv_cells_lds_quads(BW, NCQG)];
+    conv_cells_h_body<BW, NCQG, true>(in, wh, nullptr, scale, shift, res, out, CQI, COUT, relu_res, ovf, boards, bpw, s_red, s_x);
+}
 
 
 // 1x1 convs of both heads (model.py:37,56) + their BatchNorm + ReLU.

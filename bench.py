@@ -391,6 +391,8 @@ class TrainStep:
 # the averages are the same estimate, shares are avg x launches issued
 TIMING_STRIDE = 8
 TRAINED_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4_trained_9x9_4block.pt")
+# a checkpoint trained FROM SCRATCH with tools/train_omok.py --fp16-grid-weights (round 6, tools/exp/r6j.sh): its conv weights are fp16 numbers as saved
+TRAINED_GRID_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r6j_trained_fp16grid_9x9_4block.pt")
 
 
 def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.25, fp16_grid=False):
@@ -414,11 +416,13 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
     B, S, G = args.board, args.sims, args.games
     model = PVNet(args.blocks, 5, args.planes, B)
     model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+    already_on_grid = False
     if fp16_grid:
         with torch.no_grad():
-            for p in model.parameters():
-                if p.dim() == 4 and p.shape[2] == 3:
-                    p.copy_(p.to(torch.float16).to(p.dtype))
+            convs = [p for p in model.parameters() if p.dim() == 4 and p.shape[2] == 3]
+            already_on_grid = all(torch.equal(p.to(torch.float16).to(p.dtype), p) for p in convs)
+            for p in convs:
+                p.copy_(p.to(torch.float16).to(p.dtype))
     model.eval()
     net = model.to_native(local)
     products, weights_fp16 = net.products()
@@ -513,7 +517,8 @@ def trained_net_bench(args, local, path, steps=8, warm_plies=8, oversubscribe=1.
     r["weights"] = os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
     r["mfma_products"] = products
     if fp16_grid:
-        r["weights"] += " with the 3x3 conv weights rounded to the fp16 grid (tools/train_omok.py --fp16-grid-weights keeps them there)"
+        r["weights"] += (" (trained with tools/train_omok.py --fp16-grid-weights: its 3x3 conv weights are fp16 numbers as saved)" if already_on_grid else
+                         " with the 3x3 conv weights rounded to the fp16 grid (tools/train_omok.py --fp16-grid-weights keeps them there)")
     r["workload"] = ("the headline's sims / rows per simulation, network = the committed checkpoint trained by this engine "
                      "(tools/train_omok.py); plies %d-%d timed" % (warm_plies, warm_plies + steps - 1))
     if over and static:
@@ -974,6 +979,12 @@ def main():
                     if out["trained_net"].get("value"):
                         leg["vs_trained_net"] = leg["value"] / out["trained_net"]["value"]
                     out["trained_net_fp16grid"] = leg
+                    if os.path.exists(TRAINED_GRID_CKPT):
+                        # ... and a network that was TRAINED on the grid (no rounding at load time: the file's conv weights are fp16 numbers);
+                        # another network = other search depths, so this is a second data point, not the A/B of the line above
+                        own = trained_net_bench(args, local, TRAINED_GRID_CKPT, steps=6, oversubscribe=args.oversubscribe, fp16_grid=True)
+                        leg["trained_on_the_grid"] = {k: own.get(k) for k in ("weights", "value", "unit", "ms_per_step", "mfma_products", "mean_select_depth",
+                                                                               "terminal_leaf_fraction", "trunk_kernel", "trunk_avg_launch_ms", "roofline")}
                 except Exception as e:
                     out["trained_net_fp16grid"] = {"value": None, "error": repr(e)}
         if world == 1 and G > 1 and not args.no_single_game:

@@ -46,6 +46,8 @@ CASES = [
     (1, 7, 1024, 0, "k_layer16hk_w16<7, 4>"),
     (2, 9, 300, 0, "k_row16hk_w16<9>"),              # below 48 groups: one workgroup per group x output row x cout pair
     (1, 6, 500, 0, "k_row16hk_w16<6>"),
+    (2, 9, 16, 0, "k_conv_cells_h_w16<9, 8>"),       # a handful of boards: the per-board path (half the weight bytes through the CU)
+    (1, 15, 8, 0, "k_conv_cells_h_w16<15, 8>"),
     (2, 15, 96, 0, "k_boardh_w16<15, 1>"),           # wide boards: one board per workgroup, resident in LDS
     (1, 11, 130, 0, "k_boardh_w16<11, 1>"),
     (2, 15, 40, 0, "k_layer16h_w16<15>"),            # few wide boards: the per-layer kernel on column tiles
@@ -109,11 +111,14 @@ def test_arbitrary_fp32_weights_stay_on_three_products():
     net.close()
 
 
-def test_search_on_bit_planes_is_the_same_with_two_and_three_products():
+@pytest.mark.parametrize("G,kernel2,kernel3", [(3072, "k_trunk16hb_w16<9, 4, 0>", "k_trunk16hb<9, 4, 0>"),
+                                               (6, "k_conv_cells_h_w16<9, 8>", "k_conv_cells_h<9, 8>")])
+def test_search_on_bit_planes_is_the_same_with_two_and_three_products(G, kernel2, kernel3):
     """ao_search feeds the trunk the engine's bit planes (k_trunk16hb_w16 at 3072+ games; conv1 then runs ONE product: 0/1 planes
-    have no low half, fp16 weights have none either): visits, priors and moves of every game equal the three-product search."""
+    have no low half, fp16 weights have none either) -- or, for a handful of games, runs the fused per-game step around the per-board
+    convs: visits, priors and moves of every game equal the three-product search."""
     from alpha_omok_amd.engine import Engine, Net
-    B, S, G = 9, 12, 3072
+    B, S = 9, 12
     net = Net(2, 5, 128, B, 0)
     net.load_state_dict(_grid_sd(2, 128, B, 77))
     seeds = np.arange(4000, 4000 + G, dtype=np.uint32)
@@ -129,7 +134,7 @@ def test_search_on_bit_planes_is_the_same_with_two_and_three_products():
             rec.append((pi, vis, pol, act, win))
         out[products] = rec
         kname = net.dominant_kernel(G)[0]
-        assert kname.startswith("k_trunk16hb_w16<9, 4, 0>" if products == 0 else "k_trunk16hb<9, 4, 0>"), kname
+        assert kname.startswith(kernel2 if products == 0 else kernel3), kname
         eng.close()
     for a, b in zip(out[0], out[3]):
         for x, y in zip(a, b):
