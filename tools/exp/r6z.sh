@@ -35,6 +35,11 @@ for n in 32 64 256 1024; do
   python tools/time_net.py $n 10 15 0 2>/dev/null
   python tools/time_net.py $n 10 15 0 --fp16-grid 2>/dev/null
 done
+echo "# searches of a few games (tools/time_single_game.py: tree step + per-board / row kernels), three and two products"
+for g in 1 8 32 128; do
+  python tools/time_single_game.py --games $g --moves 6 2>/dev/null
+  python tools/time_single_game.py --games $g --moves 6 --fp16-grid 2>/dev/null
+done
 } > gpurun_out/r6z_forward_by_batch_two_vs_three_products.txt 2>&1
 python - <<'P'
 import json, re
