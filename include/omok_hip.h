@@ -191,9 +191,9 @@ int ao_eval_log_count(ao_engine *e);
 
 /* ---- policy/value network ---- replaces model.PVNet(...).forward in eval() mode
  * (model.py:76-104). Parameters are given under their state_dict names.
- * planes: a multiple of 32 in 32 .. 256 (model.py:76-85 takes any width). 128 planes (the reference's OUT_PLANES,
- * main.py:35) run on the split-fp16 MFMA kernels; 160 .. 256 planes on the row-chunked fp32-MFMA layer kernels for every
- * batch size, whatever ao_net_set_mode asks for. */
+ * planes: a multiple of 32 in 32 .. 512 (model.py:76-85 takes any width; the Python layer zero-pads other widths to the next
+ * multiple). 128 planes (the reference's OUT_PLANES, main.py:35) run on the split-fp16 MFMA kernels; 160 .. 512 planes on the
+ * row-chunked fp32-MFMA layer kernels for every batch size, whatever ao_net_set_mode asks for. */
 int  ao_net_create(int n_block, int inplanes, int planes, int board, int device, ao_net **out);
 void ao_net_destroy(ao_net *n);
 const char *ao_net_last_error(const ao_net *n);
