@@ -940,7 +940,8 @@ static int search_impl(ao_engine* e, ao_net* net, const uint8_t* active, const i
         const char* dev_env = getenv("AO_CATCHUP_ROUNDS");   // developer switch, read per search: cut the loop short (tests: 0 = a short search must be an error)
         const int dev_rounds = dev_env ? atoi(dev_env) : -1;
         const int max_rounds = dev_rounds >= 0 ? dev_rounds : 4 * (e->S + 2);
-        bool window_off = false;
+        bool window_off = getenv("AO_CATCHUP_WINDOW_OFF") != nullptr;   // developer switch (tests): the catch-up rounds run without a sit-out window from the start
+        if (window_off) sit_off_forced = true;
         int stalled = 0;
         for (int round = 0; round < max_rounds; ++round) {
             AO_HIP(e, hipMemcpyAsync(h_done, e->tp.sims_done, sizeof(int32_t) * G, hipMemcpyDeviceToHost, e->stream));

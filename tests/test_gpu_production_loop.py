@@ -186,6 +186,17 @@ def test_a_search_short_of_its_simulations_is_an_error_not_a_result(monkeypatch)
     assert alive.all()
     assert over.search_stats()['terminal'] > 0              # terminal leaves (which take no row) were met
     assert over.row_stats()['waits'] > 0                    # leaves DID wait: the catch-up loop had work to do
+    # the branch a stalled round takes -- nobody sits out any more (the controller's window is dropped in the middle of a move) -- forced
+    # from the first catch-up round on: the same results
+    monkeypatch.setenv("AO_CATCHUP_WINDOW_OFF", "1")
+    pi0, vis0, pol0 = ref.search(net, tau=tau)
+    pi1, vis1, pol1 = over.search(net, tau=tau)
+    monkeypatch.delenv("AO_CATCHUP_WINDOW_OFF")
+    assert np.array_equal(vis0[alive], vis1[alive]) and np.array_equal(pi0[alive], pi1[alive]) and np.array_equal(pol0[alive], pol1[alive])
+    a0, w0 = ref.play()
+    a1, w1 = over.play()
+    assert np.array_equal(a0, a1) and np.array_equal(w0, w1)
+    alive &= (w1 == 0)
     # the same engine, catch-up loop cut off
     monkeypatch.setenv("AO_CATCHUP_ROUNDS", "0")
     short = 0
